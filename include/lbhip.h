@@ -1,0 +1,141 @@
+/*
+ * lbhip.h -- C ABI of liblbhip.so, the MI355X (gfx950) latent-retrieval backend.
+ *
+ * The reference (amazedsaint/lbm) has no FFI for this path: the path is plain
+ * Python (lb/latent.py, lb/context_graph.py, lb/node.py:718-734).  Each entry
+ * point below therefore cites the reference *Python* interface it replaces;
+ * INTEGRATION.md shows the ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative LBH_E_* code on failure
+ *     and never throws; lbh_last_error() returns a thread-local message.
+ *   - all array arguments are caller-owned, caller-sized, contiguous,
+ *     little-endian.  Pointers are HOST pointers unless the name ends in _dev.
+ *   - handles are released only through lbh_shutdown / lbh_index_destroy.
+ *   - one context = one GPU (one process per GPU); an index belongs to the
+ *     context that created it.  Calls on one index are serialised internally.
+ *   - there is NO CPU fallback: without a usable gfx950 device lbh_init fails.
+ */
+#ifndef LBHIP_H
+#define LBHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBH_DIM 64          /* embedding width; lb/latent.py:41 default dim, the only one callers use */
+#define LBH_KEY_BYTES 32    /* tie-break key: raw bytes of the 64-hex claim hash (big-endian order) */
+#define LBH_MAX_PAGE 64     /* results produced per device pass; larger k is paged internally */
+
+#define LBH_OK 0
+#define LBH_E_INVALID (-1)  /* bad argument */
+#define LBH_E_DEVICE (-2)   /* HIP runtime error / no gfx950 device */
+#define LBH_E_NOMEM (-3)
+#define LBH_E_NOTFOUND (-4) /* unknown claim id */
+#define LBH_E_INTERNAL (-5)
+
+#define LBH_SINCE_NONE INT64_MIN /* since_ms value meaning "no time filter" (Python None) */
+
+typedef struct lbh_ctx lbh_ctx;
+typedef struct lbh_index lbh_index;
+
+/* Per-search statistics (all optional; pass NULL to skip).  Times are HIP-event
+ * times on the library's own stream. */
+typedef struct lbh_stats {
+    int32_t want_timing;      /* in: non-zero = record HIP events around the kernels below */
+    int32_t path;             /* out: 0 = fp32 scan + exact re-rank, 1 = exact fp64 scan (fallback / paging), 2 = batched MFMA */
+    int64_t rows_scanned;     /* out: live rows the scoring kernel read */
+    int64_t bytes_per_row;    /* out: algorithmic bytes per row for that kernel (256/264/272 or 512+..) */
+    int64_t candidates;       /* out: rows that reached the exact fp64 re-rank */
+    int32_t scan_launches;    /* out: number of scoring-kernel launches this call made */
+    int32_t fallbacks;        /* out: times the fp32 path overflowed into the exact path */
+    float scan_ms;            /* out: total HIP-event time of the scoring kernel launches */
+    float total_ms;           /* out: HIP-event time of everything enqueued by the call */
+} lbh_stats;
+
+/* ---- context -------------------------------------------------------------- */
+
+/* Bind a context to devices[0] (n_devices must be 1: one process per GPU). */
+int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx);
+int lbh_shutdown(lbh_ctx* ctx);
+const char* lbh_last_error(void);
+int lbh_version(void);
+/* Name of the device the context runs on, e.g. "gfx950:sramecc+:xnack-". */
+int lbh_device_name(lbh_ctx* ctx, char* buf, int buflen);
+
+/* ---- lb/latent.py ----------------------------------------------------------- */
+
+/* replaces lb/latent.py:41-57  embed(text, dim=64), batched.
+ * utf8 + offsets[n+1] is a CSR pack of n texts; out_f64 receives n x 64 doubles,
+ * bit-identical to the reference's Python floats.  Tokenisation (lb/latent.py:34-38),
+ * both SHA-256 digests per token (:47-48), the in-order fp64 accumulation (:50-52)
+ * and the normalisation (:54-57) all run on the GPU. */
+int lbh_embed_batch(lbh_ctx* ctx, const uint8_t* utf8, const int64_t* offsets, int64_t n, double* out_f64);
+/* Same, device pointers in and out (text already resident in HBM); out_f32_dev may be NULL. */
+int lbh_embed_batch_dev(lbh_ctx* ctx, const uint8_t* utf8_dev, const int64_t* offsets_dev, int64_t n,
+                        int64_t total_bytes, double* out_f64_dev, float* out_f32_dev);
+
+/* replaces lb/latent.py:60-63  cosine(a, b): sequential fp64 dot product, computed on
+ * the GPU.  Returns LBH_E_INVALID (message "dimension mismatch") when na != nb,
+ * which the Python mirror turns into the reference's ValueError. */
+int lbh_cosine(lbh_ctx* ctx, const double* a, int64_t na, const double* b, int64_t nb, double* out);
+
+/* ---- lb/context_graph.py ---------------------------------------------------- */
+
+/* replaces ContextGraph.__init__ (lb/context_graph.py:56-58): an empty claim index in HBM. */
+int lbh_index_create(lbh_ctx* ctx, lbh_index** out_idx);
+int lbh_index_destroy(lbh_index* idx);
+/* Pre-size the HBM arrays for `capacity` claims (optional; add grows geometrically). */
+int lbh_index_reserve(lbh_index* idx, int64_t capacity);
+
+/* replaces ContextGraph.add_claim (lb/context_graph.py:60-82) / from_snapshot's re-embedding
+ * loop (:142-147), batched.  Exactly one of (utf8, offsets) or emb_f64 supplies the vectors:
+ * texts are embedded on the GPU (same kernel as lbh_embed_batch); emb_f64 is n x 64 doubles.
+ * created_ms[n]; tagmask[n] may be NULL (= 0); hashkey is n x 32 bytes compared as big-endian
+ * integers for the (-score, claim_hash) tie-break of :120.  out_ids[n] receives stable claim ids. */
+int lbh_index_add(lbh_index* idx, int64_t n, const double* emb_f64, const uint8_t* utf8, const int64_t* offsets,
+                  const int64_t* created_ms, const uint64_t* tagmask, const uint8_t* hashkey, uint64_t* out_ids);
+
+/* replaces ContextGraph.retract (lb/context_graph.py:84-89): the row is removed from the
+ * scanned arrays (the reference drops the embedding and skips the claim, :89,:107). */
+int lbh_index_retract(lbh_index* idx, uint64_t id);
+/* Rewrites the per-claim metadata that compile() filters on (a caller mutated Claim.created_ms / tags). */
+int lbh_index_update_meta(lbh_index* idx, uint64_t id, int64_t created_ms, uint64_t tagmask, const uint8_t* hashkey);
+/* Bulk rewrite of the tie-break keys of n live claims (ids[n], hashkey n x 32 bytes).  Used by the
+ * Python mirror when claim hashes are not 64-hex strings: it then ranks the hash strings with
+ * Python's own str order (what lb/context_graph.py:120 compares) and stores the ranks as keys. */
+int lbh_index_set_keys(lbh_index* idx, int64_t n, const uint64_t* ids, const uint8_t* hashkey);
+int lbh_index_size(lbh_index* idx, int64_t* out_live);
+/* Copies the cached fp64 embedding of a claim (the reference's _embedding_cache[h]). */
+int lbh_index_get_embedding(lbh_index* idx, uint64_t id, double* out64);
+
+/* replaces the scoring loop + sort + cut of ContextGraph.compile (lb/context_graph.py:104-121)
+ * for nq query vectors (q_f64 = nq x 64 doubles, e.g. from lbh_embed_batch).
+ *   k         max(0, int(top_k)) of :121; any value (paged internally beyond LBH_MAX_PAGE)
+ *   since_ms  LBH_SINCE_NONE = None; otherwise rows with created_ms < since_ms are skipped (:110)
+ *   tag_mask  0 = no tag filter (reference behaviour); else rows need (tagmask & tag_mask) != 0
+ * Outputs, per query q: out_counts[q] results in out_ids[q*k ..] / out_scores[q*k ..], ordered
+ * exactly like the reference: score descending, then hash key ascending.  Scores are the
+ * reference's fp64 values bit-for-bit.  stats may be NULL. */
+int lbh_index_search(lbh_index* idx, const double* q_f64, int64_t nq, int64_t k, int64_t since_ms,
+                     uint64_t tag_mask, uint64_t* out_ids, double* out_scores, int64_t* out_counts,
+                     lbh_stats* stats);
+
+/* Convenience: embed(query) (:104) and the search in one call, one round trip. */
+int lbh_index_search_text(lbh_index* idx, const uint8_t* utf8, int64_t len, int64_t k, int64_t since_ms,
+                          uint64_t tag_mask, uint64_t* out_ids, double* out_scores, int64_t* out_count,
+                          double* out_qvec64, lbh_stats* stats);
+
+/* Local top-k for a claim-sharded corpus (one shard per GPU/rank): like lbh_index_search for one
+ * query, and additionally returns the 32-byte hash keys so that ranks can merge their lists with
+ * the same (-score, key) comparator after an all-gather. */
+int lbh_index_search_shard(lbh_index* idx, const double* q_f64, int64_t k, int64_t since_ms, uint64_t tag_mask,
+                           uint64_t* out_ids, double* out_scores, uint8_t* out_keys, int64_t* out_count,
+                           lbh_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBHIP_H */

@@ -1,0 +1,302 @@
+"""ctypes binding of liblbhip.so (C ABI: include/lbhip.h).
+
+This is the only door between Python and the GPU.  There is deliberately no CPU
+fallback: if the shared library is missing, or no gfx950 device can be opened,
+every entry point raises ``HipBackendError`` -- loudly, at first use.
+
+PyTorch is not needed here; where a caller wants torch to own a device buffer it
+passes ``tensor.data_ptr()`` to the ``*_dev`` entry points.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+DIM = 64
+KEY_BYTES = 32
+MAX_PAGE = 64
+SINCE_NONE = -(2 ** 63)
+INT64_MAX = 2 ** 63 - 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblbhip.so")
+
+EXPORTS = [
+    "lbh_init", "lbh_shutdown", "lbh_last_error", "lbh_version", "lbh_device_name",
+    "lbh_embed_batch", "lbh_embed_batch_dev", "lbh_cosine",
+    "lbh_index_create", "lbh_index_destroy", "lbh_index_reserve", "lbh_index_add", "lbh_index_retract",
+    "lbh_index_update_meta", "lbh_index_set_keys", "lbh_index_size", "lbh_index_get_embedding",
+    "lbh_index_search", "lbh_index_search_text", "lbh_index_search_shard",
+]
+
+
+class HipBackendError(RuntimeError):
+    """The HIP backend is unavailable or a call into it failed."""
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        ("want_timing", ctypes.c_int32), ("path", ctypes.c_int32),
+        ("rows_scanned", ctypes.c_int64), ("bytes_per_row", ctypes.c_int64), ("candidates", ctypes.c_int64),
+        ("scan_launches", ctypes.c_int32), ("fallbacks", ctypes.c_int32),
+        ("scan_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
+    ]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+_lib = None
+_lib_lock = threading.RLock()
+_ctx = None
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_u64 = ctypes.c_uint64
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen liblbhip.so and declare every prototype of include/lbhip.h.  Needs no GPU."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipBackendError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C lbm_amd/csrc`). lbm_amd has no CPU fallback.")
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # missing ROCm runtime etc.
+            raise HipBackendError(f"cannot load {LIB_PATH}: {e}") from e
+        L.lbh_last_error.restype = ctypes.c_char_p
+        L.lbh_last_error.argtypes = []
+        L.lbh_version.restype = ctypes.c_int
+        L.lbh_version.argtypes = []
+        L.lbh_init.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(_vp)]
+        L.lbh_shutdown.argtypes = [_vp]
+        L.lbh_device_name.argtypes = [_vp, ctypes.c_char_p, ctypes.c_int]
+        L.lbh_embed_batch.argtypes = [_vp, _vp, _vp, _i64, _vp]
+        L.lbh_embed_batch_dev.argtypes = [_vp, _vp, _vp, _i64, _i64, _vp, _vp]
+        L.lbh_cosine.argtypes = [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(ctypes.c_double)]
+        L.lbh_index_create.argtypes = [_vp, ctypes.POINTER(_vp)]
+        L.lbh_index_destroy.argtypes = [_vp]
+        L.lbh_index_reserve.argtypes = [_vp, _i64]
+        L.lbh_index_add.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+        L.lbh_index_retract.argtypes = [_vp, _u64]
+        L.lbh_index_update_meta.argtypes = [_vp, _u64, _i64, _u64, _vp]
+        L.lbh_index_set_keys.argtypes = [_vp, _i64, _vp, _vp]
+        L.lbh_index_size.argtypes = [_vp, ctypes.POINTER(_i64)]
+        L.lbh_index_get_embedding.argtypes = [_vp, _u64, _vp]
+        L.lbh_index_search.argtypes = [_vp, _vp, _i64, _i64, _i64, _u64, _vp, _vp, _vp, ctypes.POINTER(Stats)]
+        L.lbh_index_search_text.argtypes = [_vp, _vp, _i64, _i64, _i64, _u64, _vp, _vp, ctypes.POINTER(_i64), _vp,
+                                            ctypes.POINTER(Stats)]
+        L.lbh_index_search_shard.argtypes = [_vp, _vp, _i64, _i64, _u64, _vp, _vp, _vp, ctypes.POINTER(_i64),
+                                             ctypes.POINTER(Stats)]
+        for name in EXPORTS:
+            if name not in ("lbh_last_error", "lbh_version"):
+                getattr(L, name).restype = ctypes.c_int
+        _lib = L
+        return L
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        msg = load_library().lbh_last_error().decode("utf-8", "replace")
+        if rc == -1 and msg == "dimension mismatch":
+            raise ValueError("dimension mismatch")  # lb/latent.py:62
+        raise HipBackendError(f"liblbhip error {rc}: {msg}")
+
+
+def default_device() -> int:
+    for var in ("LBM_HIP_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            return int(v)
+    return 0
+
+
+def context():
+    """Process-wide context on one GPU (LBM_HIP_DEVICE, else LOCAL_RANK, else 0)."""
+    global _ctx
+    L = load_library()
+    with _lib_lock:
+        if _ctx is None:
+            dev = (ctypes.c_int * 1)(default_device())
+            h = _vp()
+            _check(L.lbh_init(dev, 1, ctypes.byref(h)))
+            _ctx = h
+        return _ctx
+
+
+def device_name() -> str:
+    buf = ctypes.create_string_buffer(128)
+    _check(load_library().lbh_device_name(context(), buf, 128))
+    return buf.value.decode()
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def pack_texts(texts: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
+    """UTF-8 blob + int64 CSR offsets [n+1].  Lone surrogates are kept (they are separators anyway)."""
+    enc = [t.encode("utf-8", "surrogatepass") for t in texts]
+    offsets = np.zeros(len(enc) + 1, dtype=np.int64)
+    if enc:
+        offsets[1:] = np.cumsum([len(e) for e in enc])
+    blob = np.frombuffer(b"".join(enc) + b"\x00", dtype=np.uint8).copy()
+    return blob, offsets
+
+
+def embed_batch_packed(blob: np.ndarray, offsets: np.ndarray) -> np.ndarray:
+    n = int(offsets.shape[0]) - 1
+    out = np.empty((n, DIM), dtype=np.float64)
+    if n > 0:
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        _check(load_library().lbh_embed_batch(context(), _ptr(blob), _ptr(offsets), n, _ptr(out)))
+    return out
+
+
+def embed_batch(texts: Sequence[str]) -> np.ndarray:
+    blob, offsets = pack_texts(texts)
+    return embed_batch_packed(blob, offsets)
+
+
+def embed_batch_dev(utf8_ptr: int, offsets_ptr: int, n: int, total_bytes: int, out64_ptr: int, out32_ptr: int = 0):
+    _check(load_library().lbh_embed_batch_dev(context(), utf8_ptr, offsets_ptr, n, total_bytes, out64_ptr,
+                                              out32_ptr or None))
+
+
+def cosine(a: np.ndarray, b: np.ndarray) -> float:
+    out = ctypes.c_double(0.0)
+    _check(load_library().lbh_cosine(context(), _ptr(a), a.shape[0], _ptr(b), b.shape[0], ctypes.byref(out)))
+    return out.value
+
+
+class Index:
+    """Thin owner of an ``lbh_index*`` (an HBM-resident claim index)."""
+
+    def __init__(self) -> None:
+        self._L = load_library()
+        h = _vp()
+        _check(self._L.lbh_index_create(context(), ctypes.byref(h)))
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.lbh_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reserve(self, capacity: int) -> None:
+        _check(self._L.lbh_index_reserve(self._h, int(capacity)))
+
+    def size(self) -> int:
+        out = _i64(0)
+        _check(self._L.lbh_index_size(self._h, ctypes.byref(out)))
+        return out.value
+
+    def add_texts(self, blob: np.ndarray, offsets: np.ndarray, created_ms: np.ndarray, tagmask: Optional[np.ndarray],
+                  keys: np.ndarray) -> np.ndarray:
+        n = int(offsets.shape[0]) - 1
+        ids = np.empty(n, dtype=np.uint64)
+        if n == 0:
+            return ids
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        created_ms = np.ascontiguousarray(created_ms, dtype=np.int64)
+        keys = np.ascontiguousarray(keys, dtype=np.uint8).reshape(n, KEY_BYTES)
+        if tagmask is not None:
+            tagmask = np.ascontiguousarray(tagmask, dtype=np.uint64)
+        _check(self._L.lbh_index_add(self._h, n, None, _ptr(blob), _ptr(offsets), _ptr(created_ms), _ptr(tagmask),
+                                     _ptr(keys), _ptr(ids)))
+        return ids
+
+    def add_vectors(self, emb: np.ndarray, created_ms: np.ndarray, tagmask: Optional[np.ndarray],
+                    keys: np.ndarray) -> np.ndarray:
+        emb = np.ascontiguousarray(emb, dtype=np.float64).reshape(-1, DIM)
+        n = emb.shape[0]
+        ids = np.empty(n, dtype=np.uint64)
+        if n == 0:
+            return ids
+        created_ms = np.ascontiguousarray(created_ms, dtype=np.int64)
+        keys = np.ascontiguousarray(keys, dtype=np.uint8).reshape(n, KEY_BYTES)
+        if tagmask is not None:
+            tagmask = np.ascontiguousarray(tagmask, dtype=np.uint64)
+        _check(self._L.lbh_index_add(self._h, n, _ptr(emb), None, None, _ptr(created_ms), _ptr(tagmask), _ptr(keys),
+                                     _ptr(ids)))
+        return ids
+
+    def retract(self, cid: int) -> None:
+        _check(self._L.lbh_index_retract(self._h, int(cid)))
+
+    def update_meta(self, cid: int, created_ms: int, tagmask: int, key: bytes) -> None:
+        k = np.frombuffer(key, dtype=np.uint8).copy()
+        _check(self._L.lbh_index_update_meta(self._h, int(cid), int(created_ms), int(tagmask), _ptr(k)))
+
+    def set_keys(self, ids: np.ndarray, keys: np.ndarray) -> None:
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        keys = np.ascontiguousarray(keys, dtype=np.uint8).reshape(ids.shape[0], KEY_BYTES)
+        _check(self._L.lbh_index_set_keys(self._h, ids.shape[0], _ptr(ids), _ptr(keys)))
+
+    def get_embedding(self, cid: int) -> np.ndarray:
+        out = np.empty(DIM, dtype=np.float64)
+        _check(self._L.lbh_index_get_embedding(self._h, int(cid), _ptr(out)))
+        return out
+
+    def search(self, q: np.ndarray, k: int, since_ms: int = SINCE_NONE, tag_mask: int = 0,
+               stats: Optional[Stats] = None):
+        """q: (nq, 64) float64.  Returns (ids [nq, k] uint64, scores [nq, k] float64, counts [nq] int64)."""
+        q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1, DIM)
+        nq = q.shape[0]
+        k = max(0, int(k))
+        kk = min(k, max(self.size(), 1))
+        ids = np.zeros((nq, kk), dtype=np.uint64)
+        sc = np.zeros((nq, kk), dtype=np.float64)
+        cnt = np.zeros(nq, dtype=np.int64)
+        if nq and k:
+            _check(self._L.lbh_index_search(self._h, _ptr(q), nq, kk, int(since_ms), int(tag_mask), _ptr(ids),
+                                            _ptr(sc), _ptr(cnt), ctypes.byref(stats) if stats is not None else None))
+        return ids, sc, cnt
+
+    def search_text(self, query: str, k: int, since_ms: int = SINCE_NONE, tag_mask: int = 0,
+                    stats: Optional[Stats] = None, want_qvec: bool = False):
+        b = query.encode("utf-8", "surrogatepass")
+        buf = np.frombuffer(b + b"\x00", dtype=np.uint8).copy()
+        k = max(0, int(k))
+        kk = min(k, max(self.size(), 1))
+        ids = np.zeros(max(kk, 1), dtype=np.uint64)
+        sc = np.zeros(max(kk, 1), dtype=np.float64)
+        cnt = _i64(0)
+        qv = np.zeros(DIM, dtype=np.float64) if want_qvec else None
+        _check(self._L.lbh_index_search_text(self._h, _ptr(buf), len(b), kk, int(since_ms), int(tag_mask), _ptr(ids),
+                                             _ptr(sc), ctypes.byref(cnt), _ptr(qv),
+                                             ctypes.byref(stats) if stats is not None else None))
+        n = cnt.value
+        return ids[:n], sc[:n], qv
+
+    def search_shard(self, q: np.ndarray, k: int, since_ms: int = SINCE_NONE, tag_mask: int = 0,
+                     stats: Optional[Stats] = None):
+        q = np.ascontiguousarray(q, dtype=np.float64).reshape(DIM)
+        k = max(0, int(k))
+        kk = min(k, max(self.size(), 1))
+        ids = np.zeros(max(kk, 1), dtype=np.uint64)
+        sc = np.zeros(max(kk, 1), dtype=np.float64)
+        keys = np.zeros((max(kk, 1), KEY_BYTES), dtype=np.uint8)
+        cnt = _i64(0)
+        _check(self._L.lbh_index_search_shard(self._h, _ptr(q), kk, int(since_ms), int(tag_mask), _ptr(ids), _ptr(sc),
+                                              _ptr(keys), ctypes.byref(cnt),
+                                              ctypes.byref(stats) if stats is not None else None))
+        n = cnt.value
+        return ids[:n], sc[:n], keys[:n]

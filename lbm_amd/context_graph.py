@@ -1,0 +1,428 @@
+"""Drop-in for the reference's ``lb/context_graph.py`` with the ranking on the GPU.
+
+Public surface is the reference's (lb/context_graph.py:10-148): the ``Claim``
+dataclass (+ ``to_dict`` / ``from_dict``), ``ContextGraph`` with a live
+``claims`` dict, ``_embedding_cache``, ``add_claim``, ``retract``, ``compile``,
+``snapshot`` / ``from_snapshot``.  ``compile`` gains one opt-in keyword,
+``tags=None`` (any-of tag filter, fused into the scan; absent from the
+reference, whose behaviour is the default).
+
+How the mirror works
+  * ``claims`` stays a real ``dict`` (subclass) because callers read and write
+    it directly (lb/admin.py:396-397, tests/test_multi_agent.py:160-162).  Every
+    mutation of the dict or of a ``Claim`` attribute marks that hash dirty.
+  * The device index (liblbhip.so, include/lbhip.h) holds one row per claim the
+    reference would score: present in ``claims``, not retracted, embedding
+    cached.  ``compile`` first reconciles dirty hashes -- all new texts go to the
+    GPU in ONE batched embed call (K1) -- then runs the search kernels and
+    formats the text on the host (lb/context_graph.py:122-133).
+  * Cache semantics are the reference's: the vector is computed when the claim
+    is added (``add_claim``) or first scored; later edits of ``Claim.text`` do
+    not re-embed; ``retract`` drops the vector (:89); flipping ``retracted`` or
+    deleting a dict entry by hand keeps it ("parked" on the host as fp64 bits).
+  * Tie-break keys: a 64-char lowercase-hex hash is stored as its 32 raw bytes
+    (byte order == str order).  If any other string is used as a hash, the graph
+    switches to rank keys: hashes are ranked with Python's own ``str`` order --
+    the order lb/context_graph.py:120 sorts by -- and the ranks become the keys.
+"""
+from __future__ import annotations
+
+import re
+import time
+from dataclasses import dataclass
+from typing import Any, Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _hip
+
+_HEX64 = re.compile(r"[0-9a-f]{64}\Z")
+MAX_TAG_BITS = 64
+
+
+@dataclass
+class Claim:  # lb/context_graph.py:10-43
+    claim_hash: str
+    text: str
+    tags: List[str]
+    created_ms: int
+    evidence: List[str]
+    parent_hash: Optional[str] = None  # For claim threading/conversations
+    retracted: bool = False
+
+    def __setattr__(self, name: str, value: Any) -> None:
+        object.__setattr__(self, name, value)
+        owner = self.__dict__.get("_lbm_owner")
+        if owner is not None and name in ("retracted", "created_ms", "tags", "text"):
+            owner[0]._touch(owner[1])
+
+    def to_dict(self) -> Dict[str, Any]:
+        d = {
+            "claim_hash": self.claim_hash,
+            "text": self.text,
+            "tags": list(self.tags),
+            "created_ms": int(self.created_ms),
+            "evidence": list(self.evidence),
+            "retracted": bool(self.retracted),
+        }
+        if self.parent_hash is not None:
+            d["parent_hash"] = self.parent_hash
+        return d
+
+    @staticmethod
+    def from_dict(d: Dict[str, Any]) -> "Claim":
+        return Claim(
+            claim_hash=str(d["claim_hash"]),
+            text=str(d.get("text", "")),
+            tags=list(d.get("tags", [])),
+            created_ms=int(d.get("created_ms", 0)),
+            evidence=list(d.get("evidence", [])),
+            parent_hash=d.get("parent_hash"),
+            retracted=bool(d.get("retracted", False)),
+        )
+
+
+class _ClaimDict(dict):
+    """``ContextGraph.claims``: a dict that reports which hashes changed."""
+
+    def __init__(self, graph: "ContextGraph") -> None:
+        super().__init__()
+        self._g = graph
+
+    def _adopt(self, k, v) -> None:
+        if isinstance(v, Claim):
+            v.__dict__["_lbm_owner"] = (self._g, k)
+        self._g._touch(k)
+
+    def __setitem__(self, k, v) -> None:
+        super().__setitem__(k, v)
+        self._adopt(k, v)
+
+    def __delitem__(self, k) -> None:
+        super().__delitem__(k)
+        self._g._touch(k)
+
+    def pop(self, k, *default):
+        had = k in self
+        r = super().pop(k, *default)
+        if had:
+            self._g._touch(k)
+        return r
+
+    def popitem(self):
+        k, v = super().popitem()
+        self._g._touch(k)
+        return k, v
+
+    def clear(self) -> None:
+        for k in list(self.keys()):
+            self._g._touch(k)
+        super().clear()
+
+    def setdefault(self, k, default=None):
+        if k not in self:
+            self[k] = default
+        return self[k]
+
+    def update(self, *a, **kw) -> None:
+        for k, v in dict(*a, **kw).items():
+            self[k] = v
+
+    def __ior__(self, other):
+        self.update(other)
+        return self
+
+
+class _EmbeddingCacheView:
+    """``ContextGraph._embedding_cache``: claim_hash -> embedding (list of 64 floats), read from HBM."""
+
+    def __init__(self, graph: "ContextGraph") -> None:
+        self._g = graph
+
+    def __contains__(self, h) -> bool:
+        g = self._g
+        g._sync()
+        return h in g._id_of or h in g._parked
+
+    def __getitem__(self, h) -> List[float]:
+        g = self._g
+        g._sync()
+        if h in g._id_of:
+            return g._index.get_embedding(g._id_of[h]).tolist()
+        if h in g._parked:
+            return g._parked[h].tolist()
+        raise KeyError(h)
+
+    def get(self, h, default=None):
+        try:
+            return self[h]
+        except KeyError:
+            return default
+
+    def __setitem__(self, h, vec) -> None:
+        g = self._g
+        g._sync()
+        v = np.ascontiguousarray(vec, dtype=np.float64)
+        if v.shape != (_hip.DIM,):
+            raise ValueError("embedding must have 64 components")
+        g._drop_row(h, park=False)
+        g._parked[h] = v
+        g._touch(h)
+
+    def pop(self, h, *default):
+        g = self._g
+        g._sync()
+        if h in g._id_of or h in g._parked:
+            val = self[h]
+            g._drop_row(h, park=False)
+            g._parked.pop(h, None)
+            g._touch(h)
+            return val
+        if default:
+            return default[0]
+        raise KeyError(h)
+
+    def __delitem__(self, h) -> None:
+        self.pop(h)
+
+    def keys(self) -> List[str]:
+        g = self._g
+        g._sync()
+        return list(g._id_of.keys()) + [h for h in g._parked if h not in g._id_of]
+
+    def __iter__(self) -> Iterator[str]:
+        return iter(self.keys())
+
+    def __len__(self) -> int:
+        return len(self.keys())
+
+    def items(self):
+        return [(h, self[h]) for h in self.keys()]
+
+    def clear(self) -> None:
+        for h in self.keys():
+            self.pop(h, None)
+
+
+class ContextGraph:
+    """Truth-maintenance flavored graph (v1) -- GPU-ranked drop-in (lb/context_graph.py:46-148)."""
+
+    def __init__(self) -> None:
+        self._dirty: Dict[str, None] = {}      # insertion-ordered set of hashes to reconcile
+        self._pending_text: Dict[str, str] = {}  # text captured by add_claim (embedded at next sync)
+        self._id_of: Dict[str, int] = {}       # hash -> device claim id (rows the GPU scans)
+        self._hash_of: Dict[int, str] = {}
+        self._meta: Dict[str, Tuple[int, int]] = {}  # hash -> (created_ms, tagmask) as stored on device
+        self._parked: Dict[str, np.ndarray] = {}     # cached vectors of claims currently not scanned
+        self._tag_bits: Dict[str, int] = {}
+        self._tag_overflow = False
+        self._rank_keys = False
+        self._keys_stale = False
+        self._index_obj: Optional[_hip.Index] = None
+        self.claims: Dict[str, Claim] = _ClaimDict(self)
+        self._embedding_cache = _EmbeddingCacheView(self)
+
+    # ------------------------------------------------------------------ plumbing
+
+    @property
+    def _index(self) -> _hip.Index:
+        if self._index_obj is None:
+            self._index_obj = _hip.Index()  # raises HipBackendError without liblbhip.so + MI355X
+        return self._index_obj
+
+    def _touch(self, h: str) -> None:
+        self._dirty[h] = None
+
+    def _tagmask(self, tags: Iterable[str]) -> int:
+        m = 0
+        for t in tags:
+            b = self._tag_bits.get(t)
+            if b is None:
+                if len(self._tag_bits) >= MAX_TAG_BITS:
+                    self._tag_overflow = True
+                    continue
+                b = len(self._tag_bits)
+                self._tag_bits[t] = b
+            m |= 1 << b
+        return m
+
+    def _key_bytes(self, h: str) -> bytes:
+        if not self._rank_keys and isinstance(h, str) and _HEX64.match(h):
+            return bytes.fromhex(h)
+        if not self._rank_keys:
+            self._rank_keys = True
+        self._keys_stale = True
+        return b"\x00" * _hip.KEY_BYTES  # placeholder until _refresh_rank_keys
+
+    def _refresh_rank_keys(self) -> None:
+        hs = sorted(self._id_of.keys())  # Python str order: what lb/context_graph.py:120 compares
+        if hs:
+            ids = np.array([self._id_of[h] for h in hs], dtype=np.uint64)
+            keys = np.zeros((len(hs), _hip.KEY_BYTES), dtype=np.uint8)
+            ranks = np.arange(len(hs), dtype=">u8")
+            keys[:, :8] = ranks.view(np.uint8).reshape(-1, 8)
+            self._index.set_keys(ids, keys)
+        self._keys_stale = False
+
+    def _drop_row(self, h: str, park: bool) -> None:
+        cid = self._id_of.pop(h, None)
+        if cid is None:
+            return
+        if park:
+            self._parked[h] = self._index.get_embedding(cid)
+        self._index.retract(cid)
+        self._hash_of.pop(cid, None)
+        self._meta.pop(h, None)
+
+    def _sync(self) -> None:
+        """Bring the device index in line with ``claims`` (only dirty hashes are looked at)."""
+        if not self._dirty:
+            if self._keys_stale:
+                self._refresh_rank_keys()
+            return
+        dirty, self._dirty = list(self._dirty.keys()), {}
+        new_text: List[Tuple[str, str, Claim]] = []
+        new_vec: List[Tuple[str, np.ndarray, Claim]] = []
+        for h in dirty:
+            c = self.claims.get(h)
+            live = c is not None and not getattr(c, "retracted", False)
+            if not live:
+                self._drop_row(h, park=True)
+                self._pending_text.pop(h, None)
+                continue
+            if h in self._id_of:
+                cm, tm = int(c.created_ms), self._tagmask(c.tags)
+                if self._meta.get(h) != (cm, tm):
+                    key = self._key_bytes(h) if not self._rank_keys else b"\x00" * _hip.KEY_BYTES
+                    self._index.update_meta(self._id_of[h], cm, tm, key)
+                    if self._rank_keys:
+                        self._keys_stale = True
+                    self._meta[h] = (cm, tm)
+                continue
+            if h in self._parked:
+                new_vec.append((h, self._parked.pop(h), c))
+            else:
+                new_text.append((h, self._pending_text.pop(h, c.text), c))
+        if new_vec:
+            hs = [h for h, _, _ in new_vec]
+            created = np.array([int(c.created_ms) for _, _, c in new_vec], dtype=np.int64)
+            tmask = np.array([self._tagmask(c.tags) for _, _, c in new_vec], dtype=np.uint64)
+            keys = np.frombuffer(b"".join(self._key_bytes(h) for h in hs), dtype=np.uint8)
+            ids = self._index.add_vectors(np.stack([v for _, v, _ in new_vec]), created, tmask, keys)
+            self._register(hs, ids, created, tmask)
+        if new_text:
+            hs = [h for h, _, _ in new_text]
+            blob, offsets = _hip.pack_texts([t for _, t, _ in new_text])
+            created = np.array([int(c.created_ms) for _, _, c in new_text], dtype=np.int64)
+            tmask = np.array([self._tagmask(c.tags) for _, _, c in new_text], dtype=np.uint64)
+            keys = np.frombuffer(b"".join(self._key_bytes(h) for h in hs), dtype=np.uint8)
+            ids = self._index.add_texts(blob, offsets, created, tmask, keys)
+            self._register(hs, ids, created, tmask)
+        if self._rank_keys and (self._keys_stale or new_vec or new_text):
+            self._refresh_rank_keys()
+
+    def _register(self, hs: Sequence[str], ids: np.ndarray, created: np.ndarray, tmask: np.ndarray) -> None:
+        for h, cid, cm, tm in zip(hs, ids.tolist(), created.tolist(), tmask.tolist()):
+            self._id_of[h] = cid
+            self._hash_of[cid] = h
+            self._meta[h] = (cm, tm)
+
+    # ------------------------------------------------------------------ reference API
+
+    def add_claim(
+        self,
+        claim_hash: str,
+        text: str,
+        tags: List[str],
+        evidence: Optional[List[str]] = None,
+        *,
+        created_ms: Optional[int] = None,
+        parent_hash: Optional[str] = None,
+    ) -> None:
+        if created_ms is None:
+            created_ms = int(time.time() * 1000)
+        # the reference re-embeds on every add_claim (:82), also when the hash already exists
+        self._drop_row(claim_hash, park=False)
+        self._parked.pop(claim_hash, None)
+        self._pending_text[claim_hash] = text
+        self.claims[claim_hash] = Claim(
+            claim_hash=claim_hash,
+            text=text,
+            tags=list(tags),
+            created_ms=int(created_ms),
+            evidence=list(evidence or []),
+            parent_hash=parent_hash,
+            retracted=False,
+        )
+
+    def retract(self, claim_hash: str) -> None:
+        c = self.claims.get(claim_hash)
+        if c:
+            c.retracted = True
+            # the reference frees the cached embedding here (:89)
+            self._drop_row(claim_hash, park=False)
+            self._parked.pop(claim_hash, None)
+            self._pending_text.pop(claim_hash, None)
+
+    def compile(
+        self, query: str, *, top_k: int = 8, since_ms: Optional[int] = None, tags: Optional[Sequence[str]] = None
+    ) -> Tuple[str, List[str]]:
+        """Compile context slice from claims (lb/context_graph.py:91-133).
+
+        ``tags`` (extension, default off): keep only claims carrying at least one of these tags.
+        """
+        chosen, _ = self._rank(query, top_k, since_ms, tags)
+        lines = ["Context slice", f"Query: {query}", ""]
+        for i, h in enumerate(chosen, 1):
+            c = self.claims[h]
+            tag_str = (", ".join(c.tags)) if c.tags else ""
+            if tag_str:
+                lines.append(f"{i}. {c.text}  [tags: {tag_str}]")
+            else:
+                lines.append(f"{i}. {c.text}")
+        return "\n".join(lines).strip() + "\n", chosen
+
+    def compile_scored(self, query: str, *, top_k: int = 8, since_ms: Optional[int] = None,
+                       tags: Optional[Sequence[str]] = None, stats: Optional[_hip.Stats] = None
+                       ) -> Tuple[List[str], List[float]]:
+        """Ranking only: (claim hashes, fp64 scores) in the reference's order."""
+        return self._rank(query, top_k, since_ms, tags, stats)
+
+    def _rank(self, query, top_k, since_ms, tags, stats=None) -> Tuple[List[str], List[float]]:
+        self._sync()
+        k = max(0, int(top_k))  # :121
+        if since_ms is None:
+            since = _hip.SINCE_NONE
+        else:
+            since = since_ms if isinstance(since_ms, int) else int(np.ceil(since_ms))
+            if since > _hip.INT64_MAX:
+                return [], []  # created_ms < since_ms holds for every storable timestamp
+            since = max(since, _hip.SINCE_NONE)
+        tag_mask = 0
+        if tags is not None:
+            for t in tags:
+                b = self._tag_bits.get(t)
+                if b is not None:
+                    tag_mask |= 1 << b
+                elif self._tag_overflow:
+                    raise NotImplementedError("tag filter: this graph uses more than 64 distinct tags")
+            if tag_mask == 0:
+                return [], []  # no claim carries any of the requested tags
+        index = self._index  # opens the HIP backend even for an empty graph: no silent CPU path
+        if k == 0 or not self._id_of:
+            return [], []
+        ids, scores, _ = index.search_text(query, k, since, tag_mask, stats)
+        return [self._hash_of[i] for i in ids.tolist()], scores.tolist()
+
+    def snapshot(self) -> Dict[str, Any]:
+        return {"claims": {h: c.to_dict() for h, c in self.claims.items()}}
+
+    @staticmethod
+    def from_snapshot(s: Dict[str, Any]) -> "ContextGraph":
+        """lb/context_graph.py:139-148: every non-retracted claim is re-vectorised -- here as one
+        batched K1 launch at the first ``compile`` / cache access instead of N Python ``embed`` calls."""
+        g = ContextGraph()
+        claims = s.get("claims", {}) or {}
+        for h, cd in claims.items():
+            g.claims[h] = Claim.from_dict(cd)
+        return g

@@ -1,0 +1,659 @@
+// api.hip -- host side of liblbhip.so: context, HBM-resident claim index, and the extern "C" entry
+// points declared in include/lbhip.h.  No compute happens here: every number the caller sees was
+// produced by a kernel in embed.hip / search.hip.  There is no CPU fallback.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "lbh_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess)                                                                    \
+            return fail(e__ == hipErrorOutOfMemory ? LBH_E_NOMEM : LBH_E_DEVICE, "%s: %s", #expr, \
+                        hipGetErrorString(e__));                                                  \
+    } while (0)
+
+}  // namespace
+
+struct lbh_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::string arch;
+    std::mutex mu;  // serialises use of the scratch below
+    // small scratch for embed / cosine calls
+    uint8_t* d_text = nullptr;
+    int64_t d_text_cap = 0;
+    int64_t* d_off = nullptr;
+    int64_t d_off_cap = 0;
+    double* d_vec = nullptr;  // embed output / cosine operands
+    int64_t d_vec_cap = 0;
+};
+
+struct lbh_index {
+    lbh_ctx* ctx = nullptr;
+    std::mutex mu;
+    int64_t n = 0, cap = 0;
+    float* emb32 = nullptr;
+    double* emb64 = nullptr;
+    int64_t* created = nullptr;
+    uint64_t* tags = nullptr;
+    uint64_t* keys = nullptr;
+    std::vector<uint64_t> id_of_row;
+    std::vector<int64_t> row_of_id;
+    lbh_workspace ws{};
+    void* staging = nullptr;  // pinned host staging
+    int64_t staging_cap = 0;
+};
+
+namespace {
+
+int ensure_ctx_scratch(lbh_ctx* c, int64_t text_bytes, int64_t n_off, int64_t n_vec) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (text_bytes > c->d_text_cap) {
+        if (c->d_text) hipFree(c->d_text);
+        c->d_text = nullptr;
+        int64_t cap = std::max<int64_t>(text_bytes, 1 << 16);
+        HIP_TRY(hipMalloc((void**)&c->d_text, (size_t)cap));
+        c->d_text_cap = cap;
+    }
+    if (n_off > c->d_off_cap) {
+        if (c->d_off) hipFree(c->d_off);
+        c->d_off = nullptr;
+        int64_t cap = std::max<int64_t>(n_off, 1024);
+        HIP_TRY(hipMalloc((void**)&c->d_off, (size_t)cap * 8));
+        c->d_off_cap = cap;
+    }
+    if (n_vec > c->d_vec_cap) {
+        if (c->d_vec) hipFree(c->d_vec);
+        c->d_vec = nullptr;
+        int64_t cap = std::max<int64_t>(n_vec, 1024);
+        HIP_TRY(hipMalloc((void**)&c->d_vec, (size_t)cap * 8));
+        c->d_vec_cap = cap;
+    }
+    return LBH_OK;
+}
+
+template <class T>
+int grow_array(T*& p, int64_t old_n, int64_t new_cap, int64_t per_row, hipStream_t s) {
+    T* q = nullptr;
+    HIP_TRY(hipMalloc((void**)&q, (size_t)new_cap * per_row * sizeof(T)));
+    if (p && old_n > 0) HIP_TRY(hipMemcpyAsync(q, p, (size_t)old_n * per_row * sizeof(T), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (p) hipFree(p);
+    p = q;
+    return LBH_OK;
+}
+
+int index_reserve_locked(lbh_index* ix, int64_t want) {
+    if (want <= ix->cap) return LBH_OK;
+    if (want >= (int64_t)0xFFFFFFF0ll) return fail(LBH_E_INVALID, "index capacity %lld exceeds 2^32 rows per shard", (long long)want);
+    HIP_TRY(hipSetDevice(ix->ctx->device));
+    hipStream_t s = ix->ctx->stream;
+    int rc;
+    if ((rc = grow_array(ix->emb32, ix->n, want, 64, s))) return rc;
+    if ((rc = grow_array(ix->emb64, ix->n, want, 64, s))) return rc;
+    if ((rc = grow_array(ix->created, ix->n, want, 1, s))) return rc;
+    if ((rc = grow_array(ix->tags, ix->n, want, 1, s))) return rc;
+    if ((rc = grow_array(ix->keys, ix->n, want, 4, s))) return rc;
+    ix->cap = want;
+    return LBH_OK;
+}
+
+int ensure_staging(lbh_index* ix, int64_t bytes) {
+    if (bytes <= ix->staging_cap) return LBH_OK;
+    if (ix->staging) hipHostFree(ix->staging);
+    ix->staging = nullptr;
+    int64_t cap = std::max<int64_t>(bytes, 1 << 20);
+    HIP_TRY(hipHostMalloc(&ix->staging, (size_t)cap, hipHostMallocDefault));
+    ix->staging_cap = cap;
+    return LBH_OK;
+}
+
+lbh_dev_index dev_view(const lbh_index* ix) {
+    lbh_dev_index d;
+    d.emb32 = ix->emb32;
+    d.emb64 = ix->emb64;
+    d.created = ix->created;
+    d.tags = ix->tags;
+    d.keys = ix->keys;
+    d.n = ix->n;
+    return d;
+}
+
+inline uint64_t load_be64(const uint8_t* p) {
+    uint64_t v;
+    memcpy(&v, p, 8);
+    return __builtin_bswap64(v);
+}
+inline void store_be64(uint8_t* p, uint64_t v) {
+    v = __builtin_bswap64(v);
+    memcpy(p, &v, 8);
+}
+
+struct PageOut {
+    int count = 0;
+    uint32_t rows[LBH_MAX_PAGE];
+    double scores[LBH_MAX_PAGE];
+    uint64_t keys[LBH_MAX_PAGE][4];
+};
+
+struct SearchAcc {
+    int path = 0;
+    int64_t rows_scanned = 0, bytes_per_row = 0, candidates = 0;
+    int scan_launches = 0, fallbacks = 0;
+    float scan_ms = 0.f;
+};
+
+// one device pass producing up to `page` (<= 64) results; q32/q64 must already be in the workspace
+int run_page(lbh_index* ix, int page, int64_t since_ms, uint64_t tag_mask, bool allow_fast, const lbh_cursor& cur,
+             bool timing, PageOut* out, SearchAcc* acc) {
+    lbh_ctx* c = ix->ctx;
+    hipStream_t s = c->stream;
+    const lbh_dev_index dv = dev_view(ix);
+    const int has_since = since_ms != LBH_SINCE_NONE;
+    const int grid = lbh_scan_grid(ix->n, c->n_cu);
+    bool fast = allow_fast && !cur.active;
+    for (;;) {
+        hipEvent_t e0 = timing ? c->ev[0] : nullptr, e1 = timing ? c->ev[1] : nullptr;
+        if (fast)
+            HIP_TRY(lbh_launch_search_fast(dv, ix->ws, page, has_since, since_ms, tag_mask, grid, s, e0, e1));
+        else {
+            const int xgrid = std::min(grid, 512);
+            HIP_TRY(lbh_launch_search_exact(dv, ix->ws, page, has_since, since_ms, tag_mask, cur, xgrid, s, e0, e1));
+        }
+        HIP_TRY(hipMemcpyAsync(ix->ws.result_host, ix->ws.result, sizeof(lbh_result), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const lbh_result* r = ix->ws.result_host;
+        acc->scan_launches += 1;
+        acc->rows_scanned = ix->n;
+        if (timing) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) acc->scan_ms += ms;
+        }
+        if (fast) {
+            acc->path = 0;
+            acc->bytes_per_row = 256 + (has_since ? 8 : 0) + (tag_mask ? 8 : 0);
+        } else {
+            acc->path = 1;
+            acc->bytes_per_row = 512 + (has_since ? 8 : 0) + (tag_mask ? 8 : 0);
+        }
+        if (r->overflow == 1 && fast) {  // candidate set unbounded in fp32 (mass near-ties): exact pass
+            fast = false;
+            acc->fallbacks += 1;
+            continue;
+        }
+        if (r->overflow)
+            return fail(LBH_E_INTERNAL, "exact path: more than %d claims tie on score and on the first 8 key bytes", LBH_MCAP);
+        acc->candidates += r->candidates;
+        out->count = r->count;
+        memcpy(out->rows, r->rows, sizeof(uint32_t) * r->count);
+        memcpy(out->scores, r->scores, sizeof(double) * r->count);
+        memcpy(out->keys, r->keys, sizeof(uint64_t) * 4 * r->count);
+        return LBH_OK;
+    }
+}
+
+// full search for one query whose vectors are already in ws.q32 / ws.q64
+int search_loaded(lbh_index* ix, int64_t k, int64_t since_ms, uint64_t tag_mask, uint64_t* out_ids, double* out_scores,
+                  uint8_t* out_keys, int64_t* out_count, lbh_stats* stats) {
+    lbh_ctx* c = ix->ctx;
+    const bool timing = stats && stats->want_timing;
+    SearchAcc acc;
+    int64_t got = 0;
+    if (timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    if (k > 0 && ix->n > 0) {
+        lbh_cursor cur;
+        memset(&cur, 0, sizeof cur);
+        int64_t remaining = std::min<int64_t>(k, ix->n);
+        while (remaining > 0) {
+            const int page = (int)std::min<int64_t>(remaining, LBH_MAX_PAGE);
+            PageOut po;
+            int rc = run_page(ix, page, since_ms, tag_mask, true, cur, timing, &po, &acc);
+            if (rc) return rc;
+            for (int i = 0; i < po.count; ++i) {
+                out_ids[got + i] = ix->id_of_row[po.rows[i]];
+                out_scores[got + i] = po.scores[i];
+                if (out_keys)
+                    for (int w = 0; w < 4; ++w) store_be64(out_keys + (got + i) * 32 + 8 * w, po.keys[i][w]);
+            }
+            got += po.count;
+            remaining -= po.count;
+            if (po.count < page) break;
+            cur.active = 1;
+            cur.ord = lbh_ord64(po.scores[po.count - 1]);
+            for (int w = 0; w < 4; ++w) cur.key[w] = po.keys[po.count - 1][w];
+        }
+    }
+    *out_count = got;
+    if (stats) {
+        float total = 0.f;
+        if (timing) {
+            HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+            HIP_TRY(hipEventSynchronize(c->ev[3]));
+            hipEventElapsedTime(&total, c->ev[2], c->ev[3]);
+        }
+        stats->path = acc.path;
+        stats->rows_scanned = acc.rows_scanned;
+        stats->bytes_per_row = acc.bytes_per_row;
+        stats->candidates = acc.candidates;
+        stats->scan_launches = acc.scan_launches;
+        stats->fallbacks = acc.fallbacks;
+        stats->scan_ms = acc.scan_ms;
+        stats->total_ms = total;
+    }
+    return LBH_OK;
+}
+
+int load_query(lbh_index* ix, const double* q) {
+    // q64 as given; q32 = round-to-nearest of each component (the scan copy's precision)
+    int rc = ensure_staging(ix, 1024);
+    if (rc) return rc;
+    double* hq = reinterpret_cast<double*>(ix->staging);
+    float* hf = reinterpret_cast<float*>(hq + 64);
+    for (int d = 0; d < 64; ++d) {
+        hq[d] = q[d];
+        hf[d] = (float)q[d];
+    }
+    hipStream_t s = ix->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ix->ws.q64, hq, 512, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ix->ws.q32, hf, 256, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // staging is reused by the next call
+    return LBH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* lbh_last_error(void) { return g_err.c_str(); }
+
+int lbh_version(void) { return 1; }
+
+int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx) {
+    if (!out_ctx) return fail(LBH_E_INVALID, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    if (n_devices != 1 || !devices) return fail(LBH_E_INVALID, "one context drives exactly one GPU (one process per GPU)");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(LBH_E_DEVICE, "no HIP device available (%s); liblbhip has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (devices[0] < 0 || devices[0] >= count) return fail(LBH_E_INVALID, "device %d out of range [0,%d)", devices[0], count);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, devices[0]));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(LBH_E_DEVICE, "device %d is %s; liblbhip is built for gfx950 (MI355X) only", devices[0], prop.gcnArchName);
+    lbh_ctx* c = new (std::nothrow) lbh_ctx();
+    if (!c) return fail(LBH_E_NOMEM, "out of host memory");
+    c->device = devices[0];
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->arch = prop.gcnArchName;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto& ev : c->ev) HIP_TRY(hipEventCreate(&ev));
+    *out_ctx = c;
+    return LBH_OK;
+}
+
+int lbh_shutdown(lbh_ctx* c) {
+    if (!c) return LBH_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->d_text) hipFree(c->d_text);
+    if (c->d_off) hipFree(c->d_off);
+    if (c->d_vec) hipFree(c->d_vec);
+    for (auto& ev : c->ev)
+        if (ev) hipEventDestroy(ev);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return LBH_OK;
+}
+
+int lbh_device_name(lbh_ctx* c, char* buf, int buflen) {
+    if (!c || !buf || buflen <= 0) return fail(LBH_E_INVALID, "bad argument");
+    snprintf(buf, (size_t)buflen, "%s", c->arch.c_str());
+    return LBH_OK;
+}
+
+int lbh_embed_batch(lbh_ctx* c, const uint8_t* utf8, const int64_t* offsets, int64_t n, double* out_f64) {
+    if (!c || n < 0 || (n > 0 && (!offsets || !out_f64))) return fail(LBH_E_INVALID, "bad argument");
+    if (n == 0) return LBH_OK;
+    const int64_t base = offsets[0], bytes = offsets[n] - base;
+    if (bytes < 0 || (bytes > 0 && !utf8)) return fail(LBH_E_INVALID, "bad offsets");
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t l = offsets[i + 1] - offsets[i];
+        if (l < 0 || l >= (int64_t)0x7FFFFF00) return fail(LBH_E_INVALID, "text %lld has invalid length %lld", (long long)i, (long long)l);
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ensure_ctx_scratch(c, bytes + 64, n + 1, n * 64);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    std::vector<int64_t> rel;
+    const int64_t* offp = offsets;
+    if (base != 0) {
+        rel.resize((size_t)n + 1);
+        for (int64_t i = 0; i <= n; ++i) rel[(size_t)i] = offsets[i] - base;
+        offp = rel.data();
+    }
+    if (bytes > 0) HIP_TRY(hipMemcpyAsync(c->d_text, utf8 + base, (size_t)bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_off, offp, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(lbh_launch_embed(c->d_text, c->d_off, n, c->d_vec, nullptr, s));
+    HIP_TRY(hipMemcpyAsync(out_f64, c->d_vec, (size_t)n * 64 * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return LBH_OK;
+}
+
+int lbh_embed_batch_dev(lbh_ctx* c, const uint8_t* utf8_dev, const int64_t* offsets_dev, int64_t n, int64_t total_bytes,
+                        double* out_f64_dev, float* out_f32_dev) {
+    if (!c || n < 0 || total_bytes < 0 || (n > 0 && (!offsets_dev || !out_f64_dev))) return fail(LBH_E_INVALID, "bad argument");
+    if (n == 0) return LBH_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(lbh_launch_embed(utf8_dev, offsets_dev, n, out_f64_dev, out_f32_dev, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LBH_OK;
+}
+
+int lbh_cosine(lbh_ctx* c, const double* a, int64_t na, const double* b, int64_t nb, double* out) {
+    if (!c || !out || na < 0 || nb < 0) return fail(LBH_E_INVALID, "bad argument");
+    if (na != nb) return fail(LBH_E_INVALID, "dimension mismatch");
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ensure_ctx_scratch(c, 0, 0, 2 * na + 8);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    if (na > 0) {
+        HIP_TRY(hipMemcpyAsync(c->d_vec, a, (size_t)na * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->d_vec + na, b, (size_t)na * 8, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(lbh_launch_cosine(c->d_vec, c->d_vec + na, na, c->d_vec + 2 * na, s));
+    HIP_TRY(hipMemcpyAsync(out, c->d_vec + 2 * na, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return LBH_OK;
+}
+
+int lbh_index_create(lbh_ctx* c, lbh_index** out_idx) {
+    if (!c || !out_idx) return fail(LBH_E_INVALID, "bad argument");
+    *out_idx = nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    lbh_index* ix = new (std::nothrow) lbh_index();
+    if (!ix) return fail(LBH_E_NOMEM, "out of host memory");
+    ix->ctx = c;
+    lbh_workspace& w = ix->ws;
+    HIP_TRY(hipMalloc((void**)&w.q32, 256));
+    HIP_TRY(hipMalloc((void**)&w.q64, 512));
+    HIP_TRY(hipMalloc((void**)&w.lists, (size_t)LBH_MAX_BLOCKS * LBH_LIST_CAP * 8));
+    HIP_TRY(hipMalloc((void**)&w.list_cnt, (size_t)LBH_MAX_BLOCKS * 4));
+    HIP_TRY(hipMalloc((void**)&w.xlists_ord, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 8));
+    HIP_TRY(hipMalloc((void**)&w.xlists_row, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 4));
+    HIP_TRY(hipMalloc((void**)&w.xlist_cnt, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * 4));
+    HIP_TRY(hipMalloc((void**)&w.flags, 256));
+    HIP_TRY(hipMalloc((void**)&w.result, sizeof(lbh_result)));
+    HIP_TRY(hipHostMalloc((void**)&w.result_host, sizeof(lbh_result), hipHostMallocDefault));
+    HIP_TRY(hipMemset(w.flags, 0, 256));
+    *out_idx = ix;
+    return LBH_OK;
+}
+
+int lbh_index_destroy(lbh_index* ix) {
+    if (!ix) return LBH_OK;
+    hipSetDevice(ix->ctx->device);
+    hipStreamSynchronize(ix->ctx->stream);
+    lbh_workspace& w = ix->ws;
+    void* dev[] = {ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, w.q32, w.q64, w.lists, w.list_cnt,
+                   w.xlists_ord, w.xlists_row, w.xlist_cnt, w.flags, w.result};
+    for (void* p : dev)
+        if (p) hipFree(p);
+    if (w.result_host) hipHostFree(w.result_host);
+    if (ix->staging) hipHostFree(ix->staging);
+    delete ix;
+    return LBH_OK;
+}
+
+int lbh_index_reserve(lbh_index* ix, int64_t capacity) {
+    if (!ix || capacity < 0) return fail(LBH_E_INVALID, "bad argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    return index_reserve_locked(ix, capacity);
+}
+
+int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t* utf8, const int64_t* offsets,
+                  const int64_t* created_ms, const uint64_t* tagmask, const uint8_t* hashkey, uint64_t* out_ids) {
+    if (!ix || n < 0) return fail(LBH_E_INVALID, "bad argument");
+    if (n == 0) return LBH_OK;
+    if ((emb_f64 != nullptr) == (offsets != nullptr)) return fail(LBH_E_INVALID, "pass either emb_f64 or (utf8, offsets)");
+    if (!created_ms || !hashkey) return fail(LBH_E_INVALID, "created_ms and hashkey are required");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    lbh_ctx* c = ix->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (ix->n + n > ix->cap) {
+        int64_t want = std::max<int64_t>(ix->n + n, std::max<int64_t>(1024, ix->cap + ix->cap / 2));
+        int rc = index_reserve_locked(ix, want);
+        if (rc) return rc;
+    }
+    const int64_t r0 = ix->n;
+    // per-claim metadata: created_ms | tagmask | keys (as 4 big-endian-decoded words)
+    int rc = ensure_staging(ix, n * (8 + 8 + 32));
+    if (rc) return rc;
+    int64_t* h_created = reinterpret_cast<int64_t*>(ix->staging);
+    uint64_t* h_tags = reinterpret_cast<uint64_t*>(h_created + n);
+    uint64_t* h_keys = h_tags + n;
+    memcpy(h_created, created_ms, (size_t)n * 8);
+    if (tagmask) memcpy(h_tags, tagmask, (size_t)n * 8);
+    else memset(h_tags, 0, (size_t)n * 8);
+    for (int64_t i = 0; i < n * 4; ++i) h_keys[i] = load_be64(hashkey + 8 * i);
+    HIP_TRY(hipMemcpyAsync(ix->created + r0, h_created, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ix->tags + r0, h_tags, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ix->keys + r0 * 4, h_keys, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    if (emb_f64) {
+        HIP_TRY(hipMemcpyAsync(ix->emb64 + r0 * 64, emb_f64, (size_t)n * 512, hipMemcpyHostToDevice, s));
+        HIP_TRY(lbh_launch_f64_to_f32(ix->emb64 + r0 * 64, ix->emb32 + r0 * 64, n * 64, s));
+    } else {
+        const int64_t base = offsets[0], bytes = offsets[n] - base;
+        if (bytes < 0 || (bytes > 0 && !utf8)) return fail(LBH_E_INVALID, "bad offsets");
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t l = offsets[i + 1] - offsets[i];
+            if (l < 0 || l >= (int64_t)0x7FFFFF00) return fail(LBH_E_INVALID, "text %lld has invalid length", (long long)i);
+        }
+        std::lock_guard<std::mutex> lk2(c->mu);
+        rc = ensure_ctx_scratch(c, bytes + 64, n + 1, 0);
+        if (rc) return rc;
+        std::vector<int64_t> rel;
+        const int64_t* offp = offsets;
+        if (base != 0) {
+            rel.resize((size_t)n + 1);
+            for (int64_t i = 0; i <= n; ++i) rel[(size_t)i] = offsets[i] - base;
+            offp = rel.data();
+        }
+        if (bytes > 0) HIP_TRY(hipMemcpyAsync(c->d_text, utf8 + base, (size_t)bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->d_off, offp, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(lbh_launch_embed(c->d_text, c->d_off, n, ix->emb64 + r0 * 64, ix->emb32 + r0 * 64, s));
+        HIP_TRY(hipStreamSynchronize(s));  // rel / caller buffers may go away
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint64_t id0 = (uint64_t)ix->row_of_id.size();
+    ix->row_of_id.resize(ix->row_of_id.size() + (size_t)n);
+    ix->id_of_row.resize((size_t)(r0 + n));
+    for (int64_t i = 0; i < n; ++i) {
+        ix->row_of_id[(size_t)(id0 + i)] = r0 + i;
+        ix->id_of_row[(size_t)(r0 + i)] = id0 + (uint64_t)i;
+        if (out_ids) out_ids[i] = id0 + (uint64_t)i;
+    }
+    ix->n += n;
+    return LBH_OK;
+}
+
+int lbh_index_retract(lbh_index* ix, uint64_t id) {
+    if (!ix) return fail(LBH_E_INVALID, "bad argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (id >= ix->row_of_id.size() || ix->row_of_id[(size_t)id] < 0) return fail(LBH_E_NOTFOUND, "unknown claim id %llu", (unsigned long long)id);
+    HIP_TRY(hipSetDevice(ix->ctx->device));
+    const int64_t r = ix->row_of_id[(size_t)id], last = ix->n - 1;
+    if (r != last) {
+        HIP_TRY(lbh_launch_move_row(ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, r, last, ix->ctx->stream));
+        const uint64_t moved = ix->id_of_row[(size_t)last];
+        ix->id_of_row[(size_t)r] = moved;
+        ix->row_of_id[(size_t)moved] = r;
+    }
+    ix->row_of_id[(size_t)id] = -1;
+    ix->id_of_row.pop_back();
+    ix->n -= 1;
+    return LBH_OK;
+}
+
+int lbh_index_update_meta(lbh_index* ix, uint64_t id, int64_t created_ms, uint64_t tagmask, const uint8_t* hashkey) {
+    if (!ix || !hashkey) return fail(LBH_E_INVALID, "bad argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (id >= ix->row_of_id.size() || ix->row_of_id[(size_t)id] < 0) return fail(LBH_E_NOTFOUND, "unknown claim id %llu", (unsigned long long)id);
+    HIP_TRY(hipSetDevice(ix->ctx->device));
+    const int64_t r = ix->row_of_id[(size_t)id];
+    uint64_t kw[4];
+    for (int w = 0; w < 4; ++w) kw[w] = load_be64(hashkey + 8 * w);
+    hipStream_t s = ix->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ix->created + r, &created_ms, 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ix->tags + r, &tagmask, 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ix->keys + r * 4, kw, 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return LBH_OK;
+}
+
+int lbh_index_set_keys(lbh_index* ix, int64_t n, const uint64_t* ids, const uint8_t* hashkey) {
+    if (!ix || n < 0 || (n > 0 && (!ids || !hashkey))) return fail(LBH_E_INVALID, "bad argument");
+    if (n == 0) return LBH_OK;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIP_TRY(hipSetDevice(ix->ctx->device));
+    hipStream_t s = ix->ctx->stream;
+    // download, patch, upload: the key table is 32 B/claim and this path is for small graphs
+    std::vector<uint64_t> host((size_t)ix->n * 4);
+    HIP_TRY(hipMemcpyAsync(host.data(), ix->keys, host.size() * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int64_t i = 0; i < n; ++i) {
+        if (ids[i] >= ix->row_of_id.size() || ix->row_of_id[(size_t)ids[i]] < 0)
+            return fail(LBH_E_NOTFOUND, "unknown claim id %llu", (unsigned long long)ids[i]);
+        const int64_t r = ix->row_of_id[(size_t)ids[i]];
+        for (int w = 0; w < 4; ++w) host[(size_t)r * 4 + w] = load_be64(hashkey + i * 32 + 8 * w);
+    }
+    HIP_TRY(hipMemcpyAsync(ix->keys, host.data(), host.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return LBH_OK;
+}
+
+int lbh_index_size(lbh_index* ix, int64_t* out_live) {
+    if (!ix || !out_live) return fail(LBH_E_INVALID, "bad argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    *out_live = ix->n;
+    return LBH_OK;
+}
+
+int lbh_index_get_embedding(lbh_index* ix, uint64_t id, double* out64) {
+    if (!ix || !out64) return fail(LBH_E_INVALID, "bad argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (id >= ix->row_of_id.size() || ix->row_of_id[(size_t)id] < 0) return fail(LBH_E_NOTFOUND, "unknown claim id %llu", (unsigned long long)id);
+    HIP_TRY(hipSetDevice(ix->ctx->device));
+    const int64_t r = ix->row_of_id[(size_t)id];
+    HIP_TRY(hipMemcpyAsync(out64, ix->emb64 + r * 64, 512, hipMemcpyDeviceToHost, ix->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ix->ctx->stream));
+    return LBH_OK;
+}
+
+int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, int64_t since_ms, uint64_t tag_mask,
+                     uint64_t* out_ids, double* out_scores, int64_t* out_counts, lbh_stats* stats) {
+    if (!ix || nq < 0 || (nq > 0 && (!q_f64 || !out_counts))) return fail(LBH_E_INVALID, "bad argument");
+    if (k < 0) k = 0;
+    if (k > 0 && nq > 0 && (!out_ids || !out_scores)) return fail(LBH_E_INVALID, "output arrays are NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIP_TRY(hipSetDevice(ix->ctx->device));
+    lbh_stats total;
+    memset(&total, 0, sizeof total);
+    for (int64_t q = 0; q < nq; ++q) {
+        int rc = load_query(ix, q_f64 + q * 64);
+        if (rc) return rc;
+        lbh_stats st;
+        memset(&st, 0, sizeof st);
+        st.want_timing = stats ? stats->want_timing : 0;
+        rc = search_loaded(ix, k, since_ms, tag_mask, out_ids + q * k, out_scores + q * k, nullptr, out_counts + q,
+                           stats ? &st : nullptr);
+        if (rc) return rc;
+        if (stats) {
+            total.path = st.path;
+            total.rows_scanned += st.rows_scanned;
+            total.bytes_per_row = st.bytes_per_row;
+            total.candidates += st.candidates;
+            total.scan_launches += st.scan_launches;
+            total.fallbacks += st.fallbacks;
+            total.scan_ms += st.scan_ms;
+            total.total_ms += st.total_ms;
+        }
+    }
+    if (stats) {
+        total.want_timing = stats->want_timing;
+        *stats = total;
+    }
+    return LBH_OK;
+}
+
+int lbh_index_search_text(lbh_index* ix, const uint8_t* utf8, int64_t len, int64_t k, int64_t since_ms, uint64_t tag_mask,
+                          uint64_t* out_ids, double* out_scores, int64_t* out_count, double* out_qvec64, lbh_stats* stats) {
+    if (!ix || len < 0 || (len > 0 && !utf8) || !out_count) return fail(LBH_E_INVALID, "bad argument");
+    if (len >= (int64_t)0x7FFFFF00) return fail(LBH_E_INVALID, "query too long");
+    if (k < 0) k = 0;
+    if (k > 0 && (!out_ids || !out_scores)) return fail(LBH_E_INVALID, "output arrays are NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    lbh_ctx* c = ix->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    {
+        std::lock_guard<std::mutex> lk2(c->mu);
+        int rc = ensure_ctx_scratch(c, len + 64, 2, 0);
+        if (rc) return rc;
+        rc = ensure_staging(ix, len + 64);
+        if (rc) return rc;
+        int64_t* ho = reinterpret_cast<int64_t*>(ix->staging);
+        ho[0] = 0;
+        ho[1] = len;
+        uint8_t* ht = reinterpret_cast<uint8_t*>(ho + 2);
+        if (len) memcpy(ht, utf8, (size_t)len);
+        if (len) HIP_TRY(hipMemcpyAsync(c->d_text, ht, (size_t)len, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->d_off, ho, 16, hipMemcpyHostToDevice, s));
+        // embed(query) (lb/context_graph.py:104) straight into the search workspace
+        HIP_TRY(lbh_launch_embed(c->d_text, c->d_off, 1, ix->ws.q64, ix->ws.q32, s));
+        if (out_qvec64) HIP_TRY(hipMemcpyAsync(out_qvec64, ix->ws.q64, 512, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return search_loaded(ix, k, since_ms, tag_mask, out_ids, out_scores, nullptr, out_count, stats);
+}
+
+int lbh_index_search_shard(lbh_index* ix, const double* q_f64, int64_t k, int64_t since_ms, uint64_t tag_mask,
+                           uint64_t* out_ids, double* out_scores, uint8_t* out_keys, int64_t* out_count, lbh_stats* stats) {
+    if (!ix || !q_f64 || !out_count) return fail(LBH_E_INVALID, "bad argument");
+    if (k < 0) k = 0;
+    if (k > 0 && (!out_ids || !out_scores || !out_keys)) return fail(LBH_E_INVALID, "output arrays are NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIP_TRY(hipSetDevice(ix->ctx->device));
+    int rc = load_query(ix, q_f64);
+    if (rc) return rc;
+    return search_loaded(ix, k, since_ms, tag_mask, out_ids, out_scores, out_keys, out_count, stats);
+}
+
+}  // extern "C"

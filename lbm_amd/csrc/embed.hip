@@ -1,0 +1,235 @@
+// embed.hip -- K1: batched claim vectorisation (tokenise + 2x SHA-256 per token + in-order fp64
+// accumulation + L2 normalisation), bit-identical to lb/latent.py:34-57 of the reference.
+//
+// One wave64 per claim.  Lanes play three roles in turn:
+//   1. byte classifier: 64 text bytes per step, __ballot -> token start / end bit masks
+//      ([A-Za-z0-9_]+, lb/latent.py:34; every byte >= 0x80 is a separator);
+//   2. hasher: lane l hashes token (l >> 1), variant (l & 1): sha256(t) or sha256(t + "\0")
+//      (lb/latent.py:47-48), 32 tokens = 64 digests per batch, lower-casing on the fly (:38);
+//   3. dimension owner: lane d accumulates v[d] += LUT[digest byte d] strictly in token order
+//      (:50-52), so the fp64 rounding sequence is the reference's.
+// The norm is a sequential sum over d = 0..63 (mul, then add, no FMA: this file is built with
+// -ffp-contract=off), IEEE sqrt and IEEE divide (:54-57).  Rows are written as one coalesced
+// 512-B (fp64 master) and one 256-B (fp32 scan copy) store per claim.
+#include "lbh_internal.h"
+
+namespace {
+
+__constant__ uint32_t K256[64] = {
+    0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u,
+    0xd807aa98u, 0x12835b01u, 0x243185beu, 0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u,
+    0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau,
+    0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u,
+    0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u,
+    0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,
+    0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u,
+    0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+
+constexpr int EMB_WAVES = 4;       // waves (claims in flight) per block
+constexpr int TOK_RING = 128;      // token (start, end) ring per wave
+constexpr int BATCH = 32;          // tokens hashed per batch (2 digests each = 64 lanes)
+
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+
+__device__ __forceinline__ bool is_word(uint32_t c) {
+    return (c - 'a' < 26u) || (c - 'A' < 26u) || (c - '0' < 10u) || c == '_';
+}
+
+// byte `p` of the padded message of a token: lower(tok[p]) for p < len, 0x00 for the optional NUL
+// at p == len, 0x80 at p == total, 0 elsewhere (the 64-bit length is patched in by the caller).
+__device__ __forceinline__ uint32_t msg_byte(const uint8_t* tok, int len, int total, int p) {
+    if (p < len) {
+        uint32_t c = tok[p];
+        if (c - 'A' < 26u) c += 32;
+        return c;
+    }
+    return p == total ? 0x80u : 0u;
+}
+
+__device__ __forceinline__ void sha256_compress(uint32_t st[8], uint32_t w[16]) {
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        uint32_t wi;
+        if (i < 16) {
+            wi = w[i];
+        } else {
+            uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+            uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3);
+            uint32_t s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
+            wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+            w[i & 15] = wi;
+        }
+        uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
+        uint32_t ch = (e & f) ^ (~e & g);
+        uint32_t t1 = h + S1 + ch + K256[i] + wi;
+        uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
+        uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+        uint32_t t2 = S0 + mj;
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    uint64_t b = __builtin_bit_cast(uint64_t, v);
+    uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)b, l);
+    uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), l);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
+__global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __restrict__ utf8,
+                                                                const int64_t* __restrict__ offsets, int64_t n,
+                                                                double* __restrict__ out64,
+                                                                float* __restrict__ out32) {
+    __shared__ double lut[256];
+    __shared__ int tok_start[EMB_WAVES][TOK_RING];
+    __shared__ int tok_end[EMB_WAVES][TOK_RING];
+    __shared__ uint32_t dig[EMB_WAVES][BATCH][16];  // 64 digest bytes per token, digest byte order
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    // lb/latent.py:52  (b / 127.5) - 1.0, evaluated once per block with IEEE fp64 divide
+    lut[threadIdx.x & 255] = ((double)(threadIdx.x & 255) / 127.5) - 1.0;
+    __syncthreads();
+
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int* ts = tok_start[wave];
+    int* te = tok_end[wave];
+    const uint8_t* digb = reinterpret_cast<const uint8_t*>(&dig[wave][0][0]);
+
+    for (int64_t claim = (int64_t)blockIdx.x * EMB_WAVES + wave; claim < n; claim += (int64_t)gridDim.x * EMB_WAVES) {
+        const int64_t off0 = offsets[claim];
+        const int len = (int)(offsets[claim + 1] - off0);
+        const uint8_t* text = utf8 + off0;
+        int n_started = 0, n_ended = 0, n_done = 0;
+        uint64_t carry = 0;
+        double acc = 0.0;
+
+        auto hash_batch = [&](int nb) {
+            const int t = lane >> 1, v = lane & 1;
+            const bool act = t < nb;
+            const int slot = (n_done + t) & (TOK_RING - 1);
+            const int s = act ? ts[slot] : 0;
+            const int tl = act ? te[slot] - s : 0;
+            const int total = tl + v;
+            const int nblk = act ? ((total + 9 + 63) >> 6) : 0;
+            const uint8_t* tok = text + s;
+            uint32_t st[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au,
+                              0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+            for (int blk = 0; __any(blk < nblk); ++blk) {
+                if (blk < nblk) {
+                    uint32_t w[16];
+                    const int p0 = blk * 64;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int p = p0 + 4 * i;
+                        w[i] = (msg_byte(tok, tl, total, p) << 24) | (msg_byte(tok, tl, total, p + 1) << 16) |
+                               (msg_byte(tok, tl, total, p + 2) << 8) | msg_byte(tok, tl, total, p + 3);
+                    }
+                    if (blk == nblk - 1) {
+                        w[14] = (uint32_t)(((uint64_t)total * 8ull) >> 32);
+                        w[15] = (uint32_t)((uint64_t)total * 8ull);
+                    }
+                    sha256_compress(st, w);
+                }
+            }
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dig[wave][t][v * 8 + i] = __builtin_bswap32(st[i]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < nb; ++i) acc = acc + lut[digb[i * 64 + lane]];  // token order, lane = dim
+            __builtin_amdgcn_wave_barrier();
+        };
+
+        for (int base = 0; base <= len; base += 64) {
+            const int p = base + lane;
+            const uint32_t c = (p < len) ? text[p] : 0u;
+            const uint64_t m = __ballot(is_word(c));
+            const uint64_t prev = (m << 1) | carry;
+            const uint64_t S = m & ~prev;   // token starts at this byte
+            const uint64_t E = ~m & prev;   // token ended just before this byte (exclusive end)
+            carry = m >> 63;
+            if ((S >> lane) & 1) ts[(n_started + __popcll(S & lt_mask)) & (TOK_RING - 1)] = p;
+            if ((E >> lane) & 1) te[(n_ended + __popcll(E & lt_mask)) & (TOK_RING - 1)] = p;
+            n_started += __popcll(S);
+            n_ended += __popcll(E);
+            __builtin_amdgcn_wave_barrier();
+            while (n_ended - n_done >= BATCH) {
+                hash_batch(BATCH);
+                n_done += BATCH;
+            }
+        }
+        if (n_ended > n_done) hash_batch(n_ended - n_done);
+
+        // lb/latent.py:54-57
+        double ss = 0.0;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) {
+            const double x = readlane_f64(acc, d);
+            ss = ss + x * x;
+        }
+        const double nrm = __builtin_sqrt(ss);
+        double o = 0.0;
+        if (n_ended > 0 && nrm != 0.0) o = acc / nrm;
+        out64[claim * 64 + lane] = o;
+        if (out32) out32[claim * 64 + lane] = (float)o;
+    }
+}
+
+// lb/latent.py:63  sum(x * y for x, y in zip(a, b)): one lane, strictly sequential, no FMA.
+__global__ void cosine_kernel(const double* __restrict__ a, const double* __restrict__ b, int64_t n,
+                              double* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double acc = 0.0;
+        for (int64_t i = 0; i < n; ++i) acc = acc + a[i] * b[i];
+        *out = acc;
+    }
+}
+
+__global__ void f64_to_f32_kernel(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (float)in[i];
+}
+
+// swap-delete support: copy row `src` over row `dst` in every per-claim array
+__global__ void move_row_kernel(float* emb32, double* emb64, int64_t* created, uint64_t* tags, uint64_t* keys,
+                                int64_t dst, int64_t src) {
+    const int l = threadIdx.x;
+    emb32[dst * 64 + l] = emb32[src * 64 + l];
+    emb64[dst * 64 + l] = emb64[src * 64 + l];
+    if (l < 4) keys[dst * 4 + l] = keys[src * 4 + l];
+    if (l == 4) created[dst] = created[src];
+    if (l == 5) tags[dst] = tags[src];
+}
+
+}  // namespace
+
+hipError_t lbh_launch_embed(const uint8_t* utf8_dev, const int64_t* offsets_dev, int64_t n, double* out64_dev,
+                            float* out32_dev, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + EMB_WAVES - 1) / EMB_WAVES;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    embed_kernel<<<dim3((unsigned)blocks), dim3(EMB_WAVES * 64), 0, s>>>(utf8_dev, offsets_dev, n, out64_dev, out32_dev);
+    return hipGetLastError();
+}
+
+hipError_t lbh_launch_cosine(const double* a_dev, const double* b_dev, int64_t n, double* out_dev, hipStream_t s) {
+    cosine_kernel<<<1, 64, 0, s>>>(a_dev, b_dev, n, out_dev);
+    return hipGetLastError();
+}
+
+hipError_t lbh_launch_f64_to_f32(const double* in_dev, float* out_dev, int64_t n_elems, hipStream_t s) {
+    if (n_elems <= 0) return hipSuccess;
+    int64_t blocks = (n_elems + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    f64_to_f32_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(in_dev, out_dev, n_elems);
+    return hipGetLastError();
+}
+
+hipError_t lbh_launch_move_row(float* emb32, double* emb64, int64_t* created, uint64_t* tags, uint64_t* keys,
+                               int64_t dst, int64_t src, hipStream_t s) {
+    move_row_kernel<<<1, 64, 0, s>>>(emb32, emb64, created, tags, keys, dst, src);
+    return hipGetLastError();
+}

@@ -1,0 +1,96 @@
+// lbh_internal.h -- shared declarations of liblbhip.so (not installed; C ABI is include/lbhip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lbhip.h"
+
+#define LBH_WAVE 64
+#define LBH_SCAN_THREADS 256                    // 4 waves per scan block
+#define LBH_SCAN_WAVES (LBH_SCAN_THREADS / 64)
+#define LBH_WCAP 256                            // per-wave candidate buffer (entries) in LDS
+#define LBH_LIST_CAP 256                        // per-block candidate list written to HBM
+#define LBH_MCAP 2048                           // max rows the single-block final stage sorts exactly
+#define LBH_MAX_BLOCKS 2048                     // max scan grid (lists in the workspace)
+
+// fp32 scan vs reference fp64 score: rigorous bound on |s32 - s64| is < 4e-6 for unit 64-vectors
+// (input rounding 2*2^-24 + 64 fp32 roundings, DESIGN.md "Error bound"); candidates are every row
+// within 2*eps of the k-th best fp32 score, so the exact top-k is always among them.
+#define LBH_MARGIN 1.0e-5f
+
+// ---- order-preserving integer images of floats ------------------------------------------------
+__host__ __device__ inline uint32_t lbh_ord32(float f) {
+    uint32_t b = __builtin_bit_cast(uint32_t, f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ inline float lbh_unord32(uint32_t o) {
+    uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __builtin_bit_cast(float, b);
+}
+__host__ __device__ inline uint64_t lbh_ord64(double d) {
+    uint64_t b = __builtin_bit_cast(uint64_t, d);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__host__ __device__ inline double lbh_unord64(uint64_t o) {
+    uint64_t b = (o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFull) : ~o;
+    return __builtin_bit_cast(double, b);
+}
+
+// ---- device arrays of one index (all row-major, row r at the natural offset) ------------------
+struct lbh_dev_index {
+    const float* emb32;       // n x 64 fp32   (256 B rows)  -- the scan copy
+    const double* emb64;      // n x 64 fp64   (512 B rows)  -- the master, reference bits
+    const int64_t* created;   // n
+    const uint64_t* tags;     // n
+    const uint64_t* keys;     // n x 4, word 0 most significant (big-endian image of the 32 key bytes)
+    int64_t n;
+};
+
+// cursor for paging the exact path: only rows strictly AFTER (score, key) in the reference order pass
+struct lbh_cursor {
+    int32_t active;
+    uint64_t ord;      // lbh_ord64(score)
+    uint64_t key[4];
+};
+
+// result block written by the final kernels (device) and copied to pinned host memory
+struct lbh_result {
+    int32_t count;
+    int32_t overflow;         // fp32 path could not bound its candidate set -> caller re-runs exactly
+    int32_t candidates;       // rows that were re-scored in fp64
+    int32_t pad;
+    uint32_t rows[LBH_MAX_PAGE];
+    double scores[LBH_MAX_PAGE];
+    uint64_t keys[LBH_MAX_PAGE][4];   // hash keys of the results (shard merge, paging cursor)
+};
+
+struct lbh_workspace {
+    float* q32;               // 64
+    double* q64;              // 64
+    uint64_t* lists;          // LBH_MAX_BLOCKS x LBH_LIST_CAP   (ord32<<32 | row)   fast path
+    int32_t* list_cnt;        // LBH_MAX_BLOCKS
+    uint64_t* xlists_ord;     // LBH_MAX_BLOCKS*4 x LBH_MAX_PAGE  exact path: ord64(score)
+    uint32_t* xlists_row;     // same shape: row
+    int32_t* xlist_cnt;       // LBH_MAX_BLOCKS*4
+    int32_t* flags;           // [0] overflow
+    lbh_result* result;       // device
+    lbh_result* result_host;  // pinned
+};
+
+// ---- kernel launchers (defined in the .hip files) ---------------------------------------------
+// embed.hip
+hipError_t lbh_launch_embed(const uint8_t* utf8_dev, const int64_t* offsets_dev, int64_t n, double* out64_dev,
+                            float* out32_dev, hipStream_t s);
+hipError_t lbh_launch_cosine(const double* a_dev, const double* b_dev, int64_t n, double* out_dev, hipStream_t s);
+hipError_t lbh_launch_f64_to_f32(const double* in_dev, float* out_dev, int64_t n_elems, hipStream_t s);
+hipError_t lbh_launch_move_row(float* emb32, double* emb64, int64_t* created, uint64_t* tags, uint64_t* keys,
+                               int64_t dst, int64_t src, hipStream_t s);
+// search.hip
+int lbh_scan_grid(int64_t n_rows, int n_cu);
+hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const lbh_workspace& ws, int k, int has_since,
+                                  int64_t since_ms, uint64_t tag_mask, int grid, hipStream_t s,
+                                  hipEvent_t ev0, hipEvent_t ev1);
+hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace& ws, int k, int has_since,
+                                   int64_t since_ms, uint64_t tag_mask, const lbh_cursor& cur, int grid,
+                                   hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);

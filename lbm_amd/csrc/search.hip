@@ -1,0 +1,608 @@
+// search.hip -- scoring + filtering + top-k for ContextGraph.compile (lb/context_graph.py:104-121).
+//
+// Fast path (one query, k <= 64):
+//   K2  scan_f32_kernel   streams the fp32 copy of the claim matrix once (256 B/claim), fuses the
+//                         since_ms / tag masks (+8 B / +8 B per claim), keeps a per-wave top-k
+//                         candidate buffer in LDS and emits, per block, every row whose fp32 score is
+//                         within LBH_MARGIN of the block's k-th best;
+//   K4  select_fast_kernel  (one block) finds the global k-th best fp32 score, keeps every row within
+//                         LBH_MARGIN of it, re-scores those rows from the fp64 master matrix in the
+//                         reference's exact operation order (lb/latent.py:63: products added left to
+//                         right, no FMA) and sorts them by (-score, hash key) like
+//                         lb/context_graph.py:120.  The exact top-k is provably inside that set.
+// Exact path (fallback when the fp32 candidate set cannot be bounded -- mass near-ties, e.g. an
+// empty query makes every score 0.0 -- and for result pages beyond the first 64):
+//   scan_exact_kernel / select_exact_kernel do the same with fp64 scores from the master matrix and
+//   the full (score, key) total order, optionally starting strictly after a cursor.
+//
+// This file is compiled with -ffp-contract=off: fp64 arithmetic must round like CPython floats.
+// FMAs in the fp32 scan are written explicitly (fmaf).
+#include "lbh_internal.h"
+
+namespace {
+
+constexpr uint32_t PAD_ROW = 0xFFFFFFFFu;
+
+struct WaveSync {
+    __device__ __forceinline__ void operator()() const { __builtin_amdgcn_wave_barrier(); }
+};
+struct BlockSync {
+    __device__ __forceinline__ void operator()() const { __syncthreads(); }
+};
+
+// Bitonic sort, descending, of n (power of two) u64 values in LDS by `nthreads` cooperating threads.
+template <class Sync>
+__device__ __forceinline__ void sort_desc_u64(uint64_t* buf, int n, int tid, int nthreads, Sync sync) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n >> 1); t += nthreads) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool desc = (i & k) == 0;
+                const uint64_t a = buf[i], b = buf[l];
+                if (desc ? (a < b) : (a > b)) { buf[i] = b; buf[l] = a; }
+            }
+            sync();
+        }
+    }
+}
+
+// hash-key comparison: true when key(ra) < key(rb) (big-endian integer order of the 32 key bytes)
+__device__ __forceinline__ bool key_less(const uint64_t* __restrict__ keys, uint32_t ra, uint32_t rb) {
+    const uint64_t* a = keys + (size_t)ra * 4;
+    const uint64_t* b = keys + (size_t)rb * 4;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint64_t x = a[w], y = b[w];
+        if (x != y) return x < y;
+    }
+    return false;
+}
+
+// reference order (lb/context_graph.py:120): score descending, then hash ascending
+__device__ __forceinline__ bool before_exact(uint64_t sa, uint32_t ra, uint64_t sb, uint32_t rb,
+                                             const uint64_t* __restrict__ keys) {
+    if (sa != sb) return sa > sb;
+    if (ra == rb || ra == PAD_ROW) return false;
+    if (rb == PAD_ROW) return true;
+    return key_less(keys, ra, rb);
+}
+
+template <class Sync>
+__device__ __forceinline__ void sort_exact(uint64_t* so, uint32_t* ro, int n, int tid, int nthreads,
+                                           const uint64_t* __restrict__ keys, Sync sync) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n >> 1); t += nthreads) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool fwd = (i & k) == 0;
+                const uint64_t sa = so[i], sb = so[l];
+                const uint32_t ra = ro[i], rb = ro[l];
+                const bool swap = fwd ? before_exact(sb, rb, sa, ra, keys) : before_exact(sa, ra, sb, rb, keys);
+                if (swap) { so[i] = sb; so[l] = sa; ro[i] = rb; ro[l] = ra; }
+            }
+            sync();
+        }
+    }
+}
+
+__device__ __forceinline__ int pow2_at_least(int n, int lo) {
+    int p = lo;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// exact reference score: sum(x*y) left to right starting from 0.0 (lb/latent.py:63)
+__device__ __forceinline__ double exact_dot(const double* __restrict__ q, const double* __restrict__ row) {
+    const double2* r2 = reinterpret_cast<const double2*>(row);
+    double acc = 0.0;
+#pragma unroll 8
+    for (int d = 0; d < 32; ++d) {
+        const double2 v = r2[d];
+        acc = acc + q[2 * d] * v.x;
+        acc = acc + q[2 * d + 1] * v.y;
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: fp32 streaming scan.  A wave reads one 64-row tile (16 KiB) per step as 16 fully coalesced
+// 1-KiB dwordx4 loads: lane l, load j covers floats [4c, 4c+4) of tile row 4j + g (c = l & 15,
+// g = l >> 4).  Four xor-butterfly steps inside each 16-lane row both reduce over c and transpose,
+// leaving lane (g, c) with the complete score of tile row 4c + g.  Every row goes through the same
+// reduction tree, so bit-identical rows get bit-identical scores wherever they sit.
+// ------------------------------------------------------------------------------------------------
+template <bool SINCE, bool TAGS>
+__global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_index ix, const float* __restrict__ q32,
+                                                                     int k, int64_t since_ms, uint64_t tag_mask,
+                                                                     uint64_t* __restrict__ lists,
+                                                                     int32_t* __restrict__ list_cnt,
+                                                                     int32_t* __restrict__ flags) {
+    __shared__ uint64_t wbuf[LBH_SCAN_WAVES][LBH_WCAP];
+    __shared__ uint64_t mbuf[LBH_SCAN_WAVES * LBH_WCAP];
+    __shared__ int wcnt[LBH_SCAN_WAVES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const float4 qf = reinterpret_cast<const float4*>(q32)[c];
+    const float4* __restrict__ E = reinterpret_cast<const float4*>(ix.emb32);
+    const int64_t n = ix.n;
+    const int64_t n_tiles = (n + 63) >> 6;
+    const int64_t n_vec = n * 16;
+    uint64_t* buf = wbuf[wave];
+
+    uint32_t thr = 0;  // ordered image of (k-th best so far - margin); 0 admits everything
+    int cnt = 0;
+    bool dead = false;
+
+    // sort the wave buffer, raise the threshold, drop what fell below it
+    auto compact = [&]() {
+        const int n2 = pow2_at_least(cnt, 64);
+        for (int i = cnt + lane; i < n2; i += 64) buf[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        sort_desc_u64(buf, n2, lane, 64, WaveSync());
+        if (cnt >= k) {
+            const uint32_t kth = (uint32_t)(buf[k - 1] >> 32);
+            const uint32_t nt = lbh_ord32(lbh_unord32(kth) - LBH_MARGIN);
+            if (nt > thr) thr = nt;
+            int kept = 0;
+            for (int i = lane; i < n2; i += 64)
+                kept += __popcll(__ballot(i < cnt && (uint32_t)(buf[i] >> 32) >= thr));
+            cnt = kept;
+        }
+        if (cnt > LBH_WCAP - 64) {  // more near-ties than the buffer holds: let the exact path decide
+            if (lane == 0) atomicOr(&flags[0], 1);
+            dead = true;
+            cnt = 0;
+        }
+    };
+
+    for (int64_t tile = (int64_t)blockIdx.x * LBH_SCAN_WAVES + wave; tile < n_tiles && !dead;
+         tile += (int64_t)gridDim.x * LBH_SCAN_WAVES) {
+        const int64_t v0 = tile * 1024 + lane;
+        float4 x[16];
+        if (v0 + 1024 - lane <= n_vec) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) x[j] = E[v0 + j * 64];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) x[j] = (v0 + j * 64 < n_vec) ? E[v0 + j * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int64_t myrow = tile * 64 + 4 * c + g;
+        bool valid = myrow < n;
+        if (SINCE) valid = valid && (ix.created[valid ? myrow : 0] >= since_ms);
+        if (TAGS) valid = valid && ((ix.tags[myrow < n ? myrow : 0] & tag_mask) != 0);
+
+        float p[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            p[j] = fmaf(x[j].w, qf.w, fmaf(x[j].z, qf.z, fmaf(x[j].y, qf.y, x[j].x * qf.x)));
+        // butterfly: after the step with mask m a lane keeps the rows whose bit matches its own
+        float r8[8], r4[4], r2[2];
+        const bool b8 = c & 8, b4 = c & 4, b2 = c & 2, b1 = c & 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float keep = b8 ? p[j + 8] : p[j], send = b8 ? p[j] : p[j + 8];
+            r8[j] = keep + __shfl_xor(send, 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float keep = b4 ? r8[j + 4] : r8[j], send = b4 ? r8[j] : r8[j + 4];
+            r4[j] = keep + __shfl_xor(send, 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float keep = b2 ? r4[j + 2] : r4[j], send = b2 ? r4[j] : r4[j + 2];
+            r2[j] = keep + __shfl_xor(send, 2);
+        }
+        const float keep1 = b1 ? r2[1] : r2[0], send1 = b1 ? r2[0] : r2[1];
+        const float s = keep1 + __shfl_xor(send1, 1);
+
+        const uint32_t o = lbh_ord32(s);
+        const bool pass = valid && o >= thr;
+        const uint64_t m = __ballot(pass);
+        if (m) {
+            if (pass) buf[cnt + __popcll(m & lt_mask)] = ((uint64_t)o << 32) | (uint32_t)myrow;
+            cnt += __popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            if (cnt > LBH_WCAP - 64) compact();
+        }
+    }
+    if (!dead && cnt > 0) compact();
+    if (lane == 0) wcnt[wave] = cnt;
+    __syncthreads();
+
+    // block merge: concatenate the wave lists, sort, keep everything within the margin of the block's k-th
+    int off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < LBH_SCAN_WAVES; ++w) {
+        if (w < wave) off += wcnt[w];
+        total += wcnt[w];
+    }
+    for (int i = lane; i < cnt; i += 64) mbuf[off + i] = buf[i];
+    const int n2 = pow2_at_least(total, 64);
+    for (int i = total + threadIdx.x; i < n2; i += LBH_SCAN_THREADS) mbuf[i] = 0;
+    __syncthreads();
+    if (total == 0) {
+        if (threadIdx.x == 0) list_cnt[blockIdx.x] = 0;
+        return;
+    }
+    sort_desc_u64(mbuf, n2, threadIdx.x, LBH_SCAN_THREADS, BlockSync());
+    uint32_t bthr = 0;
+    if (total >= k) bthr = lbh_ord32(lbh_unord32((uint32_t)(mbuf[k - 1] >> 32)) - LBH_MARGIN);
+    // survivors are a prefix of the sorted array
+    __shared__ int nsurv;
+    if (threadIdx.x == 0) nsurv = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < total; i += LBH_SCAN_THREADS) {
+        const bool in = (uint32_t)(mbuf[i] >> 32) >= bthr;
+        const bool next_in = (i + 1 < total) && (uint32_t)(mbuf[i + 1] >> 32) >= bthr;
+        if (in && !next_in) nsurv = i + 1;
+    }
+    __syncthreads();
+    int ns = nsurv;
+    if (ns > LBH_LIST_CAP) {
+        if (threadIdx.x == 0) atomicOr(&flags[0], 1);
+        ns = LBH_LIST_CAP;
+    }
+    for (int i = threadIdx.x; i < ns; i += LBH_SCAN_THREADS) lists[(size_t)blockIdx.x * LBH_LIST_CAP + i] = mbuf[i];
+    if (threadIdx.x == 0) list_cnt[blockIdx.x] = ns;
+}
+
+// ------------------------------------------------------------------------------------------------
+// radix select over a set of lists in HBM: returns the `krem`-th largest value among the entries
+// for which val(l, i, &v) is true.  All threads of the block call it; result is block-uniform.
+// ------------------------------------------------------------------------------------------------
+constexpr int SEL_THREADS = 1024;
+
+template <class F>
+__device__ uint64_t block_radix_select(int nlists, const int32_t* __restrict__ cnts, int nbytes, int64_t krem,
+                                       F val, int* hist, int64_t* sh_krem, int* sh_bin) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = SEL_THREADS / 64;
+    uint64_t prefix = 0, pmask = 0;
+    for (int b = nbytes - 1; b >= 0; --b) {
+        for (int t = tid; t < 256; t += SEL_THREADS) hist[t] = 0;
+        __syncthreads();
+        for (int l = wave; l < nlists; l += nwaves) {
+            const int cn = cnts[l];
+            for (int i = lane; i < cn; i += 64) {
+                uint64_t v;
+                if (val(l, i, &v) && (v & pmask) == prefix) atomicAdd(&hist[(int)((v >> (8 * b)) & 255)], 1);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int64_t rem = krem;
+            int bin = 255;
+            for (; bin > 0; --bin) {
+                const int h = hist[bin];
+                if (h >= rem) break;
+                rem -= h;
+            }
+            *sh_krem = rem;
+            *sh_bin = bin;
+        }
+        __syncthreads();
+        krem = *sh_krem;
+        prefix |= (uint64_t)(*sh_bin) << (8 * b);
+        pmask |= 0xFFull << (8 * b);
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// shared tail of both final kernels: rows[0..M) -> exact scores -> exact sort -> result
+// `ebuf` is >= 3 * LBH_MCAP u64 of LDS: [0, MCAP) ord64 scores, then MCAP u32 rows.
+__device__ void rerank_and_emit(uint64_t* xo, uint32_t* xr, int M, int k, const lbh_dev_index& ix,
+                                const double* qs, lbh_result* __restrict__ res, bool have_scores) {
+    const int tid = threadIdx.x;
+    const int n2 = pow2_at_least(M, 2);
+    if (!have_scores) {
+        for (int j = tid; j < M; j += SEL_THREADS) xo[j] = lbh_ord64(exact_dot(qs, ix.emb64 + (size_t)xr[j] * 64));
+    }
+    for (int j = M + tid; j < n2; j += SEL_THREADS) { xo[j] = 0; xr[j] = PAD_ROW; }
+    __syncthreads();
+    sort_exact(xo, xr, n2, tid, SEL_THREADS, ix.keys, BlockSync());
+    const int cnt = M < k ? M : k;
+    if (tid < cnt) {
+        const uint32_t r = xr[tid];
+        res->rows[tid] = r;
+        res->scores[tid] = lbh_unord64(xo[tid]);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) res->keys[tid][w] = ix.keys[(size_t)r * 4 + w];
+    }
+    if (tid == 0) { res->count = cnt; res->overflow = 0; res->candidates = M; }
+}
+
+// K4 (fast path): global fp32 threshold, candidate cut, exact fp64 re-rank.
+__global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index ix, const double* __restrict__ q64,
+                                                                   int k, int nlists,
+                                                                   const uint64_t* __restrict__ lists,
+                                                                   const int32_t* __restrict__ list_cnt,
+                                                                   const int32_t* __restrict__ flags,
+                                                                   lbh_result* __restrict__ res) {
+    __shared__ uint64_t sbuf[2 * LBH_MCAP];      // 32 KB: entries, later (ord64 | rows)
+    __shared__ int pref[LBH_MAX_BLOCKS + 1];
+    __shared__ double qs[64];
+    __shared__ int hist[256];
+    __shared__ int64_t sh_krem;
+    __shared__ int sh_bin, sh_cnt;
+    const int tid = threadIdx.x;
+
+    if (flags[0]) {
+        if (tid == 0) { res->count = 0; res->overflow = 1; res->candidates = 0; }
+        return;
+    }
+    if (tid < 64) qs[tid] = q64[tid];
+    if (tid == 0) {  // nlists <= 2048: a serial prefix sum is ~2 us; keeps the kernel simple
+        int a = 0;
+        for (int l = 0; l < nlists; ++l) { pref[l] = a; a += list_cnt[l]; }
+        pref[nlists] = a;
+        sh_cnt = 0;
+    }
+    __syncthreads();
+    const int E = pref[nlists];
+    int M = 0;
+    uint32_t thr = 0;
+    if (E <= 2 * LBH_MCAP) {
+        for (int l = tid; l < nlists; l += SEL_THREADS) {
+            const int c0 = pref[l], cn = pref[l + 1] - c0;
+            for (int i = 0; i < cn; ++i) sbuf[c0 + i] = lists[(size_t)l * LBH_LIST_CAP + i];
+        }
+        const int n2 = pow2_at_least(E, 2);
+        for (int i = E + tid; i < n2; i += SEL_THREADS) sbuf[i] = 0;
+        __syncthreads();
+        sort_desc_u64(sbuf, n2, tid, SEL_THREADS, BlockSync());
+        if (E >= k) thr = lbh_ord32(lbh_unord32((uint32_t)(sbuf[k - 1] >> 32)) - LBH_MARGIN);
+        for (int i = tid; i < E; i += SEL_THREADS) {
+            const bool in = (uint32_t)(sbuf[i] >> 32) >= thr;
+            const bool next_in = (i + 1 < E) && (uint32_t)(sbuf[i + 1] >> 32) >= thr;
+            if (in && !next_in) sh_cnt = i + 1;
+        }
+        __syncthreads();
+        M = sh_cnt;
+    } else {
+        if (E >= k) {
+            auto val = [&](int l, int i, uint64_t* v) {
+                *v = lists[(size_t)l * LBH_LIST_CAP + i] >> 32;
+                return true;
+            };
+            const uint32_t kth = (uint32_t)block_radix_select(nlists, list_cnt, 4, k, val, hist, &sh_krem, &sh_bin);
+            thr = lbh_ord32(lbh_unord32(kth) - LBH_MARGIN);
+        }
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int l = wave; l < nlists; l += SEL_THREADS / 64) {
+            const int cn = list_cnt[l];
+            for (int i = lane; i < cn; i += 64) {
+                const uint64_t e = lists[(size_t)l * LBH_LIST_CAP + i];
+                if ((uint32_t)(e >> 32) >= thr) {
+                    const int pos = atomicAdd(&sh_cnt, 1);
+                    if (pos < 2 * LBH_MCAP) sbuf[pos] = e;
+                }
+            }
+        }
+        __syncthreads();
+        M = sh_cnt;
+    }
+    if (M > LBH_MCAP) {
+        if (tid == 0) { res->count = 0; res->overflow = 1; res->candidates = M; }
+        return;
+    }
+    // rows out of sbuf into registers, then re-use sbuf as (ord64[MCAP], rows[MCAP])
+    uint32_t myrows[2];
+    myrows[0] = tid < M ? (uint32_t)sbuf[tid] : PAD_ROW;
+    myrows[1] = tid + SEL_THREADS < M ? (uint32_t)sbuf[tid + SEL_THREADS] : PAD_ROW;
+    __syncthreads();
+    uint64_t* xo = sbuf;
+    uint32_t* xr = reinterpret_cast<uint32_t*>(sbuf + LBH_MCAP);
+    if (tid < M) xr[tid] = myrows[0];
+    if (tid + SEL_THREADS < M) xr[tid + SEL_THREADS] = myrows[1];
+    __syncthreads();
+    rerank_and_emit(xo, xr, M, k, ix, qs, res, false);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact path.  One lane per row: 64 sequential fp64 multiply-adds in the reference's order.
+// Per-wave top-k under the full (score desc, key asc) order, so ties never overflow a buffer.
+// ------------------------------------------------------------------------------------------------
+template <bool SINCE, bool TAGS>
+__global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_exact_kernel(lbh_dev_index ix, const double* __restrict__ q64,
+                                                                       int k, int64_t since_ms, uint64_t tag_mask,
+                                                                       lbh_cursor cur,
+                                                                       uint64_t* __restrict__ xl_ord,
+                                                                       uint32_t* __restrict__ xl_row,
+                                                                       int32_t* __restrict__ xl_cnt) {
+    __shared__ uint64_t wo[LBH_SCAN_WAVES][LBH_WCAP];
+    __shared__ uint32_t wr[LBH_SCAN_WAVES][LBH_WCAP];
+    __shared__ double qs[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (threadIdx.x < 64) qs[threadIdx.x] = q64[threadIdx.x];
+    __syncthreads();
+    uint64_t* bo = wo[wave];
+    uint32_t* br = wr[wave];
+    const int64_t n = ix.n;
+    const int64_t n_tiles = (n + 63) >> 6;
+    int cnt = 0;
+    bool have_thr = false;
+    uint64_t thr_ord = 0;
+    uint32_t thr_row = PAD_ROW;
+
+    auto compact = [&]() {
+        const int n2 = pow2_at_least(cnt, 64);
+        for (int i = cnt + lane; i < n2; i += 64) { bo[i] = 0; br[i] = PAD_ROW; }
+        __builtin_amdgcn_wave_barrier();
+        sort_exact(bo, br, n2, lane, 64, ix.keys, WaveSync());
+        if (cnt >= k) {
+            cnt = k;
+            have_thr = true;
+            thr_ord = bo[k - 1];
+            thr_row = br[k - 1];
+        }
+    };
+
+    for (int64_t tile = (int64_t)blockIdx.x * LBH_SCAN_WAVES + wave; tile < n_tiles;
+         tile += (int64_t)gridDim.x * LBH_SCAN_WAVES) {
+        const int64_t myrow = tile * 64 + lane;
+        bool valid = myrow < n;
+        const int64_t r = valid ? myrow : 0;
+        if (SINCE) valid = valid && (ix.created[r] >= since_ms);
+        if (TAGS) valid = valid && ((ix.tags[r] & tag_mask) != 0);
+        uint64_t o = 0;
+        if (valid) o = lbh_ord64(exact_dot(qs, ix.emb64 + (size_t)r * 64));
+        if (valid && cur.active) {  // strictly after the cursor in (score desc, key asc) order
+            if (o > cur.ord) valid = false;
+            else if (o == cur.ord) {
+                const uint64_t* kk = ix.keys + (size_t)r * 4;
+                bool greater = false, decided = false;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    if (!decided && kk[w] != cur.key[w]) { greater = kk[w] > cur.key[w]; decided = true; }
+                valid = greater;
+            }
+        }
+        bool pass = valid;
+        if (pass && have_thr) pass = before_exact(o, (uint32_t)r, thr_ord, thr_row, ix.keys);
+        const uint64_t m = __ballot(pass);
+        if (m) {
+            if (pass) {
+                const int pos = cnt + __popcll(m & lt_mask);
+                bo[pos] = o;
+                br[pos] = (uint32_t)r;
+            }
+            cnt += __popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            if (cnt > LBH_WCAP - 64) compact();
+        }
+    }
+    if (cnt > 0) compact();
+    const size_t li = (size_t)blockIdx.x * LBH_SCAN_WAVES + wave;
+    for (int i = lane; i < cnt; i += 64) {
+        xl_ord[li * LBH_MAX_PAGE + i] = bo[i];
+        xl_row[li * LBH_MAX_PAGE + i] = br[i];
+    }
+    if (lane == 0) xl_cnt[li] = cnt;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void select_exact_kernel(lbh_dev_index ix, int k, int nlists,
+                                                                    const uint64_t* __restrict__ xl_ord,
+                                                                    const uint32_t* __restrict__ xl_row,
+                                                                    const int32_t* __restrict__ xl_cnt,
+                                                                    lbh_result* __restrict__ res) {
+    __shared__ uint64_t sbuf[2 * LBH_MCAP];
+    __shared__ int hist[256];
+    __shared__ int64_t sh_krem;
+    __shared__ int sh_bin, sh_cnt, sh_gt, sh_eq, sh_total;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = SEL_THREADS / 64;
+    if (tid == 0) { sh_cnt = 0; sh_gt = 0; sh_eq = 0; sh_total = 0; }
+    __syncthreads();
+    for (int l = tid; l < nlists; l += SEL_THREADS) atomicAdd(&sh_total, xl_cnt[l]);
+    __syncthreads();
+    const int E = sh_total;
+    uint64_t* xo = sbuf;
+    uint32_t* xr = reinterpret_cast<uint32_t*>(sbuf + LBH_MCAP);
+
+    uint64_t kth = 0;       // admit everything unless there are more than k entries
+    uint64_t key0_cut = ~0ull;
+    bool use_key_cut = false;
+    if (E > LBH_MCAP) {
+        auto val = [&](int l, int i, uint64_t* v) { *v = xl_ord[(size_t)l * LBH_MAX_PAGE + i]; return true; };
+        kth = block_radix_select(nlists, xl_cnt, 8, k, val, hist, &sh_krem, &sh_bin);
+        for (int l = wave; l < nlists; l += nwaves) {
+            const int cn = xl_cnt[l];
+            for (int i = lane; i < cn; i += 64) {
+                const uint64_t o = xl_ord[(size_t)l * LBH_MAX_PAGE + i];
+                if (o > kth) atomicAdd(&sh_gt, 1);
+                else if (o == kth) atomicAdd(&sh_eq, 1);
+            }
+        }
+        __syncthreads();
+        if (sh_gt + sh_eq > LBH_MCAP) {
+            // mass tie on the k-th score: cut the tie group by the first key word (ascending)
+            const int64_t need = k - sh_gt;
+            auto kval = [&](int l, int i, uint64_t* v) {
+                if (xl_ord[(size_t)l * LBH_MAX_PAGE + i] != kth) return false;
+                *v = ~ix.keys[(size_t)xl_row[(size_t)l * LBH_MAX_PAGE + i] * 4];
+                return true;
+            };
+            key0_cut = ~block_radix_select(nlists, xl_cnt, 8, need, kval, hist, &sh_krem, &sh_bin);
+            use_key_cut = true;
+        }
+    }
+    for (int l = wave; l < nlists; l += nwaves) {
+        const int cn = xl_cnt[l];
+        for (int i = lane; i < cn; i += 64) {
+            const uint64_t o = xl_ord[(size_t)l * LBH_MAX_PAGE + i];
+            const uint32_t r = xl_row[(size_t)l * LBH_MAX_PAGE + i];
+            bool in = o >= kth;
+            if (in && use_key_cut && o == kth) in = ix.keys[(size_t)r * 4] <= key0_cut;
+            if (in) {
+                const int pos = atomicAdd(&sh_cnt, 1);
+                if (pos < LBH_MCAP) { xo[pos] = o; xr[pos] = r; }
+            }
+        }
+    }
+    __syncthreads();
+    const int M = sh_cnt;
+    if (M > LBH_MCAP) {
+        if (tid == 0) { res->count = 0; res->overflow = 2; res->candidates = M; }
+        return;
+    }
+    rerank_and_emit(xo, xr, M, k, ix, nullptr, res, true);
+}
+
+}  // namespace
+
+int lbh_scan_grid(int64_t n_rows, int n_cu) {
+    const int64_t tiles = (n_rows + 63) / 64;
+    int64_t blocks = (tiles + LBH_SCAN_WAVES - 1) / LBH_SCAN_WAVES;
+    const int64_t cap = (int64_t)n_cu * 4 < LBH_MAX_BLOCKS ? (int64_t)n_cu * 4 : LBH_MAX_BLOCKS;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const lbh_workspace& ws, int k, int has_since,
+                                  int64_t since_ms, uint64_t tag_mask, int grid, hipStream_t s, hipEvent_t ev0,
+                                  hipEvent_t ev1) {
+    hipError_t e = hipMemsetAsync(ws.flags, 0, 16, s);
+    if (e != hipSuccess) return e;
+    if (ev0) hipEventRecord(ev0, s);
+    const dim3 g(grid), b(LBH_SCAN_THREADS);
+    if (has_since && tag_mask)
+        scan_f32_kernel<true, true><<<g, b, 0, s>>>(ix, ws.q32, k, since_ms, tag_mask, ws.lists, ws.list_cnt, ws.flags);
+    else if (has_since)
+        scan_f32_kernel<true, false><<<g, b, 0, s>>>(ix, ws.q32, k, since_ms, tag_mask, ws.lists, ws.list_cnt, ws.flags);
+    else if (tag_mask)
+        scan_f32_kernel<false, true><<<g, b, 0, s>>>(ix, ws.q32, k, since_ms, tag_mask, ws.lists, ws.list_cnt, ws.flags);
+    else
+        scan_f32_kernel<false, false><<<g, b, 0, s>>>(ix, ws.q32, k, since_ms, tag_mask, ws.lists, ws.list_cnt, ws.flags);
+    if (ev1) hipEventRecord(ev1, s);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, ws.q64, k, grid, ws.lists, ws.list_cnt, ws.flags, ws.result);
+    return hipGetLastError();
+}
+
+hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace& ws, int k, int has_since,
+                                   int64_t since_ms, uint64_t tag_mask, const lbh_cursor& cur, int grid,
+                                   hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if (ev0) hipEventRecord(ev0, s);
+    const dim3 g(grid), b(LBH_SCAN_THREADS);
+    if (has_since && tag_mask)
+        scan_exact_kernel<true, true><<<g, b, 0, s>>>(ix, ws.q64, k, since_ms, tag_mask, cur, ws.xlists_ord, ws.xlists_row, ws.xlist_cnt);
+    else if (has_since)
+        scan_exact_kernel<true, false><<<g, b, 0, s>>>(ix, ws.q64, k, since_ms, tag_mask, cur, ws.xlists_ord, ws.xlists_row, ws.xlist_cnt);
+    else if (tag_mask)
+        scan_exact_kernel<false, true><<<g, b, 0, s>>>(ix, ws.q64, k, since_ms, tag_mask, cur, ws.xlists_ord, ws.xlists_row, ws.xlist_cnt);
+    else
+        scan_exact_kernel<false, false><<<g, b, 0, s>>>(ix, ws.q64, k, since_ms, tag_mask, cur, ws.xlists_ord, ws.xlists_row, ws.xlist_cnt);
+    if (ev1) hipEventRecord(ev1, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    select_exact_kernel<<<1, SEL_THREADS, 0, s>>>(ix, k, grid * LBH_SCAN_WAVES, ws.xlists_ord, ws.xlists_row, ws.xlist_cnt, ws.result);
+    return hipGetLastError();
+}

@@ -1,0 +1,251 @@
+"""GPU parity tests: the HIP path (through the C ABI / the Python mirror) against the golden vectors
+generated from the reference and against the CPU oracle on seeded inputs.  Bit-exact everywhere:
+embeddings, scores, hash lists, order, context text."""
+import numpy as np
+import pytest
+
+from oracle import lb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from lbm_amd import _hip
+    assert "gfx950" in _hip.device_name()
+    return _hip
+
+
+def hexes(v):
+    return [float(x).hex() for x in v]
+
+
+def test_embed_golden_bit_exact(hip, golden_embed):
+    from lbm_amd.latent import embed, embed_many, _tokenize
+    texts = [c["text"] for c in golden_embed["embed"]]
+    batch = embed_many(texts)
+    for i, c in enumerate(golden_embed["embed"]):
+        assert hexes(batch[i]) == c["embedding"], c["text"][:40]
+        assert _tokenize(c["text"]) == c["tokens"]
+    for c in golden_embed["embed"][:12]:
+        e = embed(c["text"])
+        assert isinstance(e, list) and len(e) == 64 and hexes(e) == c["embedding"]
+    assert embed("hello")[0].hex() == "-0x1.2e0984b25fcebp-3"
+
+
+def test_embed_random_texts_vs_oracle(hip):
+    rng = np.random.default_rng(5)
+    alphabet = list("abcXYZ019_ -.,!\n\té日") + ["😀"]
+    texts = []
+    for i in range(3000):
+        n = int(rng.integers(0, 400))
+        texts.append("".join(rng.choice(alphabet, size=n)))
+    texts += ["a" * n for n in (53, 54, 55, 56, 57, 63, 64, 65, 119, 120, 121, 183, 184, 4000)]
+    texts += [" ".join("tok%d" % j for j in range(n)) for n in (31, 32, 33, 63, 64, 65, 127, 128, 129, 1000)]
+    got = hip.embed_batch(texts)
+    want = orc.embed_batch(texts)
+    assert got.tobytes() == want.tobytes()
+
+
+def test_cosine_golden(hip, golden_embed):
+    from lbm_amd.latent import cosine, embed
+    for c in golden_embed["cosine"]:
+        assert cosine(embed(c["a"]), embed(c["b"])).hex() == c["cosine"]
+    with pytest.raises(ValueError, match="dimension mismatch"):
+        cosine([1.0, 2.0], [1.0])
+    assert cosine([], []) == 0.0
+    a = np.random.default_rng(1).standard_normal(300)
+    b = np.random.default_rng(2).standard_normal(300)
+    assert cosine(list(a), list(b)).hex() == orc.cosine(a, b).hex()
+
+
+def _replay(ops):
+    from lbm_amd.context_graph import Claim, ContextGraph
+    g = ContextGraph()
+    for op in ops:
+        if op[0] == "add":
+            g.add_claim(op[1], op[2], op[3], created_ms=op[4])
+        elif op[0] == "retract":
+            g.retract(op[1])
+        elif op[0] == "raw_insert":
+            g.claims[op[1]] = Claim(claim_hash=op[1], text=op[2], tags=list(op[3]), created_ms=op[4], evidence=[])
+    return g
+
+
+def test_compile_golden_cases(hip, golden_compile):
+    for case in golden_compile:
+        g = _replay(case["ops"])
+        for r in case["results"]:
+            kw = {k: r[k] for k in ("top_k", "since_ms") if k in r}
+            text, hashes = g.compile(r["query"], **kw)
+            assert hashes == r["hashes"], (case["name"], r["query"], kw)
+            assert text == r["context"], (case["name"], r["query"], kw)
+            hs, sc = g.compile_scored(r["query"], **kw)
+            assert hexes(sc) == r["scores"], (case["name"], r["query"], kw)
+
+
+def test_compile_golden_interleaved_queries(hip, golden_compile):
+    """Queries between mutations: the device mirror must follow add / overwrite / retract incrementally."""
+    from lbm_amd.context_graph import ContextGraph
+    g, og = ContextGraph(), orc.OracleGraph()
+    case = [c for c in golden_compile if c["name"] == "overwrite_retract_raw"][0]
+    for op in case["ops"]:
+        if op[0] == "add":
+            g.add_claim(op[1], op[2], op[3], created_ms=op[4]); og.add_claim(op[1], op[2], op[3], created_ms=op[4])
+        elif op[0] == "retract":
+            g.retract(op[1]); og.retract(op[1])
+        else:
+            continue
+        for q in ("beta", "gamma delta", ""):
+            assert g.compile(q, top_k=5) == og.compile(q, top_k=5)
+
+
+def test_compile_synth2k_golden(hip, golden_synth):
+    from lbm_amd.context_graph import ContextGraph
+    import hashlib
+    d = golden_synth
+    g = ContextGraph()
+    for i in range(d["n"]):
+        tags = ["t%02d" % j for j in range(64) if (d["tagmask"][i] >> j) & 1]
+        g.add_claim(d["hashes"][i], d["texts"][i], tags, created_ms=d["created_ms"][i])
+    for i in range(d["n"]):
+        if d["retracted"][i]:
+            g.retract(d["hashes"][i])
+    for i_str, hx in d["embedding_samples"].items():
+        h = d["hashes"][int(i_str)]
+        if not d["retracted"][int(i_str)]:
+            assert hexes(g._embedding_cache[h]) == hx
+    for r in d["results"]:
+        kw = {"top_k": r["top_k"]}
+        if r["since_ms"] is not None:
+            kw["since_ms"] = r["since_ms"]
+        text, hs = g.compile(r["query"], **kw)
+        assert hs == r["hashes"], (r["query"], kw)
+        assert hashlib.sha256(text.encode()).hexdigest() == r["context_sha256"]
+        _, sc = g.compile_scored(r["query"], **kw)
+        assert hexes(sc) == r["scores"]
+
+
+def test_node_compile_context_contract(hip):
+    from lbm_amd.node import NodeError, RetrievalNode
+    node = RetrievalNode()
+    with pytest.raises(NodeError, match="unknown group_id nope"):
+        node.compile_context("nope", "q")
+    gid = node.create_group("g1")
+    g = node.groups[gid].graph
+    # tests/test_multi_agent.py:155-168 of the reference
+    g.add_claim("old_claim", "Old claim", ["old"], created_ms=5000)
+    g.add_claim("new_claim", "New claim about query", ["new"], created_ms=15000)
+    context, hashes = node.compile_context(gid, "query", top_k=10, since_ms=5001)
+    assert "new_claim" in hashes and "old_claim" not in hashes
+    assert (context, hashes) == g.compile("query", top_k=10, since_ms=5001)
+    assert context.startswith("Context slice\nQuery: query\n\n1. New claim about query  [tags: new]")
+
+
+def test_cache_view_and_direct_mutation_semantics(hip):
+    from lbm_amd.context_graph import Claim, ContextGraph
+    g, og = ContextGraph(), orc.OracleGraph()
+    for gg in (g, og):
+        gg.add_claim("h1", "alpha beta", ["a"], created_ms=1)
+        gg.add_claim("h2", "beta gamma", [], created_ms=2)
+    assert "h1" in g._embedding_cache and "zz" not in g._embedding_cache
+    assert hexes(g._embedding_cache["h1"]) == hexes(og._embedding_cache["h1"])
+    assert len(g._embedding_cache) == 2
+    # flipping the flag by hand keeps the cached vector (reference: cache untouched, claim skipped)
+    g.claims["h1"].retracted = True; og.claims["h1"].retracted = True
+    assert g.compile("beta") == og.compile("beta")
+    assert "h1" in g._embedding_cache
+    g.claims["h1"].text = "changed text is NOT re-embedded while cached"; og.claims["h1"].text = g.claims["h1"].text
+    g.claims["h1"].retracted = False; og.claims["h1"].retracted = False
+    assert g.compile("alpha") == og.compile("alpha")
+    # created_ms edits are honoured at the next compile
+    g.claims["h2"].created_ms = 100; og.claims["h2"].created_ms = 100
+    assert g.compile("beta", since_ms=50) == og.compile("beta", since_ms=50)
+    # retract() drops the vector; popping the cache forces a re-embed of the current text
+    g.retract("h2"); og.retract("h2")
+    assert "h2" not in g._embedding_cache
+    g._embedding_cache.pop("h1"); og._embedding_cache.pop("h1")
+    assert g.compile("changed") == og.compile("changed")
+    del g.claims["h1"]; del og.claims["h1"]
+    assert g.compile("changed") == og.compile("changed") == ("Context slice\nQuery: changed\n", [])
+
+
+def _arrays_case(n, seed, dup_frac=0.002):
+    from lbm_amd import synth
+    ch = synth.make_chunk(0, n, seed=seed, real_sha_keys=False, dup_frac=dup_frac)
+    return ch
+
+
+def test_index_vs_oracle_200k(hip):
+    """C-ABI level: 200k synthetic claims, fast path / paging / filters / tag mask, all bit-exact."""
+    from lbm_amd import synth
+    ch = _arrays_case(200_000, 77)
+    ix = hip.Index()
+    ids = ix.add_texts(ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)
+    assert ids.tolist() == list(range(ch.n)) and ix.size() == ch.n
+    for i in np.nonzero(ch.retracted)[0].tolist():
+        ix.retract(i)
+    assert ix.size() == ch.n - int(ch.retracted.sum())
+    emb = orc.embed_batch_packed(ch.blob, ch.offsets)
+    for i in (0, 1, 12345, ch.n - 1):
+        if not ch.retracted[i]:
+            assert ix.get_embedding(i).tobytes() == emb[i].tobytes()
+    keys_hex = ch.hashes()
+    packed = orc.pack_texts(keys_hex)
+    retr = ch.retracted.astype(np.uint8)
+    queries = synth.make_queries(6, seed=11) + [ch.text(4242), ""]
+    p50, p90 = int(ch.created_ms[ch.n // 2]), int(ch.created_ms[(9 * ch.n) // 10])
+    st = hip.Stats()
+    for qi, qtext in enumerate(queries):
+        qv = orc.embed_array(qtext)
+        assert hip.embed_batch([qtext])[0].tobytes() == qv.tobytes()
+        for k, since, tmask in ((8, None, 0), (64, p50, 0), (8, p90, 0), (200, None, 0), (8, None, 0b1011), (64, p50, 1 << 63 | 5)):
+            if qtext == "" and k == 200:
+                continue
+            want_idx, want_sc = orc.compile_arrays(emb, ch.created_ms, retr, None, qv, k, since, ch.tagmask, tmask, packed_keys=packed)
+            gi, gs, cnt = ix.search(qv[None, :], k, hip.SINCE_NONE if since is None else since, tmask, st)
+            n = int(cnt[0])
+            assert gi[0, :n].tolist() == want_idx.tolist(), (qi, k, since, tmask)
+            assert gs[0, :n].tobytes() == want_sc.tobytes(), (qi, k, since, tmask)
+            if qtext == "":
+                assert st.fallbacks >= 1 and st.path == 1  # all scores 0.0: pure hash order via the exact path
+            elif k <= 64:
+                assert st.path == 0 and st.fallbacks == 0 and st.candidates >= n
+    # text entry point == vector entry point
+    gi, gs, _ = ix.search_text(queries[0], 8)
+    gi2, gs2, _ = ix.search(orc.embed_array(queries[0])[None, :], 8)
+    assert gi.tolist() == gi2[0].tolist() and gs.tobytes() == gs2[0].tobytes()
+    ix.close()
+
+
+def test_mass_duplicates_and_ties(hip):
+    """5000 copies of one text + noise: exact ties far beyond any candidate buffer, resolved by hash."""
+    from lbm_amd.context_graph import ContextGraph
+    rng = np.random.default_rng(3)
+    g, og = ContextGraph(), orc.OracleGraph()
+    import hashlib
+    for i in range(6000):
+        h = hashlib.sha256(b"k%d" % i).hexdigest()
+        text = "identical duplicate text body" if i % 6 else "noise %d words here" % int(rng.integers(0, 50))
+        for gg in (g, og):
+            gg.add_claim(h, text, ["d"] if i % 2 else [], created_ms=1000 + i)
+    for q, kw in (("duplicate text", {"top_k": 8}), ("duplicate text", {"top_k": 300}), ("", {"top_k": 64}),
+                  ("noise", {"top_k": 64, "since_ms": 4000}), ("identical duplicate text body", {"top_k": 64, "since_ms": 6990})):
+        assert g.compile(q, **kw) == og.compile(q, **kw), (q, kw)
+        assert g.compile_scored(q, **kw)[1] == og.compile_scored(q, **kw)[1]
+
+
+def test_tags_extension_matches_oracle(hip):
+    from lbm_amd.context_graph import ContextGraph
+    from lbm_amd import synth
+    ch = synth.make_chunk(0, 4000, seed=5)
+    g, og = ContextGraph(), orc.OracleGraph()
+    texts, hashes = ch.texts(), ch.hashes()
+    for i in range(ch.n):
+        for gg in (g, og):
+            gg.add_claim(hashes[i], texts[i], ch.tags(i), created_ms=int(ch.created_ms[i]))
+    for q in synth.make_queries(3, seed=2):
+        for tags in (["t03"], ["t10", "t11", "t63"], ["unknown"], []):
+            assert g.compile(q, top_k=16, tags=tags) == og.compile(q, top_k=16, tags=tags), (q, tags)
+        assert g.compile(q, top_k=16, tags=["t00"], since_ms=int(ch.created_ms[2000])) == \
+            og.compile(q, top_k=16, tags=["t00"], since_ms=int(ch.created_ms[2000]))
