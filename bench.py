@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- claims scored/sec of compile_context's ranking on MI355X (BASELINE.json metric).
+
+Workload (``config.workload``): a synthetic claim corpus (SURVEY.md §8d distribution) of
+``--claims`` claims PER GPU (default 10 M, the size the metric is quoted on), resident in HBM;
+one step = one single-query top-k search over the whole corpus: K2 fp32 scan with the LDS
+top-k, K4 exact fp64 re-rank, and for N > 1 the all-gather merge of the per-GPU lists.
+value = claims scored per second over all GPUs = (claims per GPU * N * steps) / wall time,
+wall time = max over ranks between two barrier + synchronize brackets.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (scan_f32_kernel): algorithmic bytes = live rows * 256 B per launch,
+                divided by the kernel's mean HIP-event duration on the library's stream.
+  cpu_baseline  the CPU oracle (oracle/lb_oracle.c, a port of the reference's algorithm) timed on
+                one host core on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--claims", type=int, default=10_000_000, help="claims per GPU")
+    p.add_argument("--top-k", type=int, default=8)
+    p.add_argument("--since", choices=["none", "p50", "p90"], default="none")
+    p.add_argument("--queries", type=int, default=64)
+    p.add_argument("--cpu-sample", type=int, default=1_000_000, help="claims in the CPU-baseline sample (0 = skip)")
+    return p.parse_args()
+
+
+def cpu_baseline(sample_claims: int, top_k: int):
+    """Oracle (port of lb/latent.py + ContextGraph.compile) on 1 core, bounded sample."""
+    from lbm_amd import synth
+    from oracle import lb_oracle as orc
+    ch = synth.make_chunk(0, sample_claims, seed=1234, chunk_index=0, real_sha_keys=False)
+    t0 = time.perf_counter()
+    emb = orc.embed_batch_packed(ch.blob, ch.offsets)
+    t_embed = time.perf_counter() - t0
+    packed = orc.pack_texts(ch.hashes())
+    retr = ch.retracted.astype(np.uint8)
+    queries = synth.make_queries(8, seed=4321)
+    qv = [orc.embed_array(q) for q in queries]
+    t0 = time.perf_counter()
+    for v in qv:
+        orc.compile_arrays(emb, ch.created_ms, retr, None, v, top_k, None, packed_keys=packed)
+    t_rank = time.perf_counter() - t0
+    live = int((~ch.retracted).sum())
+    return {
+        "value": live * len(qv) / t_rank, "unit": "claims scored/s", "cores": 1, "kind": "port",
+        "sample": f"{sample_claims} claims ({live} live) x {len(qv)} queries, top_k={top_k}: "
+                  f"score every claim in fp64 + full sort like the reference ({t_rank:.2f} s); "
+                  f"embedding the sample took {t_embed:.2f} s = {sample_claims / t_embed:.0f} claims/s",
+        "embed_claims_per_s": sample_claims / t_embed,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("LBM_HIP_DEVICE", str(local_rank))
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from lbm_amd import _hip, synth
+    from lbm_amd.sharded import ShardedSearcher
+
+    # ---- build this rank's shard in HBM (texts -> K1 on the GPU) -------------------------------
+    ix = _hip.Index()
+    ix.reserve(args.claims)
+    chunk = 1_000_000
+    n_chunks = (args.claims + chunk - 1) // chunk
+    t_gen = t_add = 0.0
+    created_p50 = created_p90 = None
+    done = 0
+    for ci in range(n_chunks):
+        m = min(chunk, args.claims - done)
+        t0 = time.perf_counter()
+        ch = synth.make_chunk(rank * args.claims + done, m, seed=1234, chunk_index=rank * n_chunks + ci,
+                              real_sha_keys=False)
+        t1 = time.perf_counter()
+        ids = ix.add_texts(ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)
+        for i in np.nonzero(ch.retracted)[0].tolist():
+            ix.retract(int(ids[i]))
+        t2 = time.perf_counter()
+        t_gen += t1 - t0
+        t_add += t2 - t1
+        done += m
+    live = ix.size()
+    base = synth.BASE_MS + 1000 * rank * args.claims
+    since = {"none": _hip.SINCE_NONE, "p50": base + 1000 * (args.claims // 2),
+             "p90": base + 1000 * (9 * args.claims // 10)}[args.since]
+
+    queries = synth.make_queries(args.queries, seed=4321)
+    qvecs = _hip.embed_batch(queries)
+    searcher = ShardedSearcher(ix.search_shard, rank, world, device=torch.device("cuda", local_rank))
+    stats = _hip.Stats()
+    stats.want_timing = 1
+
+    def step(i):
+        q = qvecs[i % len(queries)]
+        if world == 1:
+            return ix.search_shard(q, args.top_k, since, 0, stats)
+        return searcher.search(q, args.top_k, since, 0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    scan_ms, lat = 0.0, []
+    fallbacks = cands = 0
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        s0 = time.perf_counter()
+        step(i)
+        lat.append(time.perf_counter() - s0)
+        if world == 1:
+            scan_ms += stats.scan_ms
+            fallbacks += stats.fallbacks
+            cands += stats.candidates
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        lv = torch.tensor([live], dtype=torch.int64, device="cuda")
+        dist.all_reduce(lv, op=dist.ReduceOp.SUM)
+        total_live = int(lv.item())
+    else:
+        total_live = live
+
+    if world > 1:  # roofline leg needs per-kernel timing: measure locally, outside the timed region
+        for i in range(min(args.steps, 50)):
+            ix.search_shard(qvecs[i % len(queries)], args.top_k, since, 0, stats)
+            scan_ms += stats.scan_ms
+        n_timed = min(args.steps, 50)
+    else:
+        n_timed = args.steps
+
+    if rank == 0:
+        bytes_per_row = 256 + (8 if args.since != "none" else 0)
+        avg_scan_s = scan_ms / 1e3 / max(n_timed, 1)
+        achieved = live * bytes_per_row / avg_scan_s / 1e9 if avg_scan_s > 0 else 0.0
+        out = {
+            "metric": "claims scored/sec (compile_context ranking, single query, top-k)",
+            "value": total_live * args.steps / elapsed,
+            "unit": "claims/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 scan + f64 exact re-rank", "data": "synthetic",
+            "config": {"workload": f"{args.claims}-claim shard per GPU (synthetic Zipf corpus, 1% retracted), "
+                                   f"single-query compile_context ranking, top_k={args.top_k}, since_ms={args.since}",
+                       "claims_per_gpu": args.claims, "live_claims_total": total_live, "top_k": args.top_k,
+                       "parallelism": f"claim-sharded x{world}, all-gather top-k merge" if world > 1 else "single GPU"},
+            "latency_ms": {"p50": float(np.percentile(lat, 50) * 1e3), "p99": float(np.percentile(lat, 99) * 1e3)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "scan_f32_kernel",
+                         "bytes_per_claim": bytes_per_row, "avg_kernel_us": avg_scan_s * 1e6},
+            "vectorise": {"claims_per_s_incl_h2d": args.claims / t_add if t_add > 0 else None,
+                          "host_text_generation_s": t_gen},
+            "fp32_fallbacks": fallbacks, "avg_candidates": cands / max(args.steps, 1),
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.top_k)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
