@@ -65,6 +65,11 @@ int lbh_version(void);
 /* Name of the device the context runs on, e.g. "gfx950:sramecc+:xnack-". */
 int lbh_device_name(lbh_ctx* ctx, char* buf, int buflen);
 
+/* Tuning knobs (no reference counterpart).  name: "scan_blocks_per_cu" (1..8, default 4),
+ * "scan_nt" (0/1: non-temporal loads in the fp32 scan).  Also read from the environment at
+ * lbh_init as LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT. */
+int lbh_set_option(lbh_ctx* ctx, const char* name, int64_t value);
+
 /* ---- lb/latent.py ----------------------------------------------------------- */
 
 /* replaces lb/latent.py:41-57  embed(text, dim=64), batched.

@@ -26,7 +26,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblbhip.so")
 
 EXPORTS = [
-    "lbh_init", "lbh_shutdown", "lbh_last_error", "lbh_version", "lbh_device_name",
+    "lbh_init", "lbh_shutdown", "lbh_last_error", "lbh_version", "lbh_device_name", "lbh_set_option",
     "lbh_embed_batch", "lbh_embed_batch_dev", "lbh_cosine",
     "lbh_index_create", "lbh_index_destroy", "lbh_index_reserve", "lbh_index_add", "lbh_index_retract",
     "lbh_index_update_meta", "lbh_index_set_keys", "lbh_index_size", "lbh_index_get_embedding",
@@ -80,6 +80,7 @@ def load_library() -> ctypes.CDLL:
         L.lbh_init.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(_vp)]
         L.lbh_shutdown.argtypes = [_vp]
         L.lbh_device_name.argtypes = [_vp, ctypes.c_char_p, ctypes.c_int]
+        L.lbh_set_option.argtypes = [_vp, ctypes.c_char_p, _i64]
         L.lbh_embed_batch.argtypes = [_vp, _vp, _vp, _i64, _vp]
         L.lbh_embed_batch_dev.argtypes = [_vp, _vp, _vp, _i64, _i64, _vp, _vp]
         L.lbh_cosine.argtypes = [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(ctypes.c_double)]
@@ -131,6 +132,10 @@ def context():
             _check(L.lbh_init(dev, 1, ctypes.byref(h)))
             _ctx = h
         return _ctx
+
+
+def set_option(name: str, value: int) -> None:
+    _check(load_library().lbh_set_option(context(), name.encode(), int(value)))
 
 
 def device_name() -> str:

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -42,6 +43,8 @@ struct lbh_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::string arch;
+    int scan_blocks_per_cu = 2;  // tuning knobs (env LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT), see DESIGN.md
+    int scan_nt = 1;
     std::mutex mu;  // serialises use of the scratch below
     // small scratch for embed / cosine calls
     uint8_t* d_text = nullptr;
@@ -64,6 +67,8 @@ struct lbh_index {
     std::vector<uint64_t> id_of_row;
     std::vector<int64_t> row_of_id;
     lbh_workspace ws{};
+    lbh_qarg qarg{};              // current query when it came from the host (kernel argument)
+    const double* qptr = nullptr;  // current query when it was embedded on the GPU (ws.q64), else NULL
     void* staging = nullptr;  // pinned host staging
     int64_t staging_cap = 0;
 };
@@ -174,17 +179,16 @@ int run_page(lbh_index* ix, int page, int64_t since_ms, uint64_t tag_mask, bool 
     hipStream_t s = c->stream;
     const lbh_dev_index dv = dev_view(ix);
     const int has_since = since_ms != LBH_SINCE_NONE;
-    const int grid = lbh_scan_grid(ix->n, c->n_cu);
+    const int grid = lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu);
     bool fast = allow_fast && !cur.active;
     for (;;) {
         hipEvent_t e0 = timing ? c->ev[0] : nullptr, e1 = timing ? c->ev[1] : nullptr;
         if (fast)
-            HIP_TRY(lbh_launch_search_fast(dv, ix->ws, page, has_since, since_ms, tag_mask, grid, s, e0, e1));
+            HIP_TRY(lbh_launch_search_fast(dv, ix->ws, ix->qptr, ix->qarg, page, has_since, since_ms, tag_mask, grid, c->scan_nt, s, e0, e1));
         else {
             const int xgrid = std::min(grid, 512);
-            HIP_TRY(lbh_launch_search_exact(dv, ix->ws, page, has_since, since_ms, tag_mask, cur, xgrid, s, e0, e1));
+            HIP_TRY(lbh_launch_search_exact(dv, ix->ws, ix->qptr, ix->qarg, page, has_since, since_ms, tag_mask, cur, xgrid, s, e0, e1));
         }
-        HIP_TRY(hipMemcpyAsync(ix->ws.result_host, ix->ws.result, sizeof(lbh_result), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         const lbh_result* r = ix->ws.result_host;
         acc->scan_launches += 1;
@@ -268,19 +272,8 @@ int search_loaded(lbh_index* ix, int64_t k, int64_t since_ms, uint64_t tag_mask,
 }
 
 int load_query(lbh_index* ix, const double* q) {
-    // q64 as given; q32 = round-to-nearest of each component (the scan copy's precision)
-    int rc = ensure_staging(ix, 1024);
-    if (rc) return rc;
-    double* hq = reinterpret_cast<double*>(ix->staging);
-    float* hf = reinterpret_cast<float*>(hq + 64);
-    for (int d = 0; d < 64; ++d) {
-        hq[d] = q[d];
-        hf[d] = (float)q[d];
-    }
-    hipStream_t s = ix->ctx->stream;
-    HIP_TRY(hipMemcpyAsync(ix->ws.q64, hq, 512, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ix->ws.q32, hf, 256, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));  // staging is reused by the next call
+    memcpy(ix->qarg.q, q, sizeof ix->qarg.q);  // travels to the GPU inside the kernel-argument segment
+    ix->qptr = nullptr;
     return LBH_OK;
 }
 
@@ -311,6 +304,8 @@ int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx) {
     c->device = devices[0];
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->arch = prop.gcnArchName;
+    if (const char* e1 = getenv("LBH_SCAN_BLOCKS_PER_CU")) c->scan_blocks_per_cu = std::max(1, std::min(8, atoi(e1)));
+    if (const char* e2 = getenv("LBH_SCAN_NT")) c->scan_nt = atoi(e2) != 0;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& ev : c->ev) HIP_TRY(hipEventCreate(&ev));
@@ -335,6 +330,15 @@ int lbh_shutdown(lbh_ctx* c) {
 int lbh_device_name(lbh_ctx* c, char* buf, int buflen) {
     if (!c || !buf || buflen <= 0) return fail(LBH_E_INVALID, "bad argument");
     snprintf(buf, (size_t)buflen, "%s", c->arch.c_str());
+    return LBH_OK;
+}
+
+int lbh_set_option(lbh_ctx* c, const char* name, int64_t value) {
+    if (!c || !name) return fail(LBH_E_INVALID, "bad argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!strcmp(name, "scan_blocks_per_cu")) c->scan_blocks_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(8, value));
+    else if (!strcmp(name, "scan_nt")) c->scan_nt = value != 0;
+    else return fail(LBH_E_INVALID, "unknown option %s", name);
     return LBH_OK;
 }
 
@@ -401,16 +405,14 @@ int lbh_index_create(lbh_ctx* c, lbh_index** out_idx) {
     if (!ix) return fail(LBH_E_NOMEM, "out of host memory");
     ix->ctx = c;
     lbh_workspace& w = ix->ws;
-    HIP_TRY(hipMalloc((void**)&w.q32, 256));
     HIP_TRY(hipMalloc((void**)&w.q64, 512));
-    HIP_TRY(hipMalloc((void**)&w.lists, (size_t)LBH_MAX_BLOCKS * LBH_LIST_CAP * 8));
-    HIP_TRY(hipMalloc((void**)&w.list_cnt, (size_t)LBH_MAX_BLOCKS * 4));
-    HIP_TRY(hipMalloc((void**)&w.xlists_ord, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 8));
-    HIP_TRY(hipMalloc((void**)&w.xlists_row, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 4));
-    HIP_TRY(hipMalloc((void**)&w.xlist_cnt, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * 4));
+    HIP_TRY(hipMalloc((void**)&w.cand, (size_t)LBH_MAX_BLOCKS * LBH_LIST_CAP * 8));
+    HIP_TRY(hipMalloc((void**)&w.xcand_ord, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 8));
+    HIP_TRY(hipMalloc((void**)&w.xcand_row, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 4));
     HIP_TRY(hipMalloc((void**)&w.flags, 256));
-    HIP_TRY(hipMalloc((void**)&w.result, sizeof(lbh_result)));
-    HIP_TRY(hipHostMalloc((void**)&w.result_host, sizeof(lbh_result), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&w.result_host, sizeof(lbh_result), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void**)&w.result_dev, w.result_host, 0));
+    memset(w.result_host, 0, sizeof(lbh_result));
     HIP_TRY(hipMemset(w.flags, 0, 256));
     *out_idx = ix;
     return LBH_OK;
@@ -421,8 +423,8 @@ int lbh_index_destroy(lbh_index* ix) {
     hipSetDevice(ix->ctx->device);
     hipStreamSynchronize(ix->ctx->stream);
     lbh_workspace& w = ix->ws;
-    void* dev[] = {ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, w.q32, w.q64, w.lists, w.list_cnt,
-                   w.xlists_ord, w.xlists_row, w.xlist_cnt, w.flags, w.result};
+    void* dev[] = {ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, w.q64, w.cand, w.xcand_ord, w.xcand_row,
+                   w.flags};
     for (void* p : dev)
         if (p) hipFree(p);
     if (w.result_host) hipHostFree(w.result_host);
@@ -637,9 +639,14 @@ int lbh_index_search_text(lbh_index* ix, const uint8_t* utf8, int64_t len, int64
         if (len) HIP_TRY(hipMemcpyAsync(c->d_text, ht, (size_t)len, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(c->d_off, ho, 16, hipMemcpyHostToDevice, s));
         // embed(query) (lb/context_graph.py:104) straight into the search workspace
-        HIP_TRY(lbh_launch_embed(c->d_text, c->d_off, 1, ix->ws.q64, ix->ws.q32, s));
-        if (out_qvec64) HIP_TRY(hipMemcpyAsync(out_qvec64, ix->ws.q64, 512, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(lbh_launch_embed(c->d_text, c->d_off, 1, ix->ws.q64, nullptr, s));
+        ix->qptr = ix->ws.q64;
+        if (out_qvec64) {
+            HIP_TRY(hipMemcpyAsync(out_qvec64, ix->ws.q64, 512, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+        // no sync otherwise: the scan is stream-ordered behind the embed kernel, and the staging
+        // area is only rewritten under ix->mu after this search's final synchronize
     }
     return search_loaded(ix, k, since_ms, tag_mask, out_ids, out_scores, nullptr, out_count, stats);
 }

@@ -54,6 +54,11 @@ struct lbh_cursor {
     uint64_t key[4];
 };
 
+// the query vector as a kernel argument (512 B of the 4 KB kernarg segment): no H2D copy per search
+struct lbh_qarg {
+    double q[64];
+};
+
 // result block written by the final kernels (device) and copied to pinned host memory
 struct lbh_result {
     int32_t count;
@@ -66,16 +71,13 @@ struct lbh_result {
 };
 
 struct lbh_workspace {
-    float* q32;               // 64
-    double* q64;              // 64
-    uint64_t* lists;          // LBH_MAX_BLOCKS x LBH_LIST_CAP   (ord32<<32 | row)   fast path
-    int32_t* list_cnt;        // LBH_MAX_BLOCKS
-    uint64_t* xlists_ord;     // LBH_MAX_BLOCKS*4 x LBH_MAX_PAGE  exact path: ord64(score)
-    uint32_t* xlists_row;     // same shape: row
-    int32_t* xlist_cnt;       // LBH_MAX_BLOCKS*4
-    int32_t* flags;           // [0] overflow
-    lbh_result* result;       // device
-    lbh_result* result_host;  // pinned
+    double* q64;              // 64: query embedded on the GPU (search_text); vector queries travel as kernargs
+    uint64_t* cand;           // flat, LBH_MAX_BLOCKS x LBH_LIST_CAP entries (ord32<<32 | row)   fast path
+    uint64_t* xcand_ord;      // flat, LBH_MAX_BLOCKS*4 x LBH_MAX_PAGE entries: ord64(score)     exact path
+    uint32_t* xcand_row;      // same shape: row
+    int32_t* flags;           // [0] overflow, [1] entries in cand, [2] entries in xcand (zeroed per launch)
+    lbh_result* result_host;  // pinned, device-mapped host memory: the final kernel writes it directly
+    lbh_result* result_dev;   // device-side address of result_host
 };
 
 // ---- kernel launchers (defined in the .hip files) ---------------------------------------------
@@ -87,10 +89,12 @@ hipError_t lbh_launch_f64_to_f32(const double* in_dev, float* out_dev, int64_t n
 hipError_t lbh_launch_move_row(float* emb32, double* emb64, int64_t* created, uint64_t* tags, uint64_t* keys,
                                int64_t dst, int64_t src, hipStream_t s);
 // search.hip
-int lbh_scan_grid(int64_t n_rows, int n_cu);
-hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const lbh_workspace& ws, int k, int has_since,
-                                  int64_t since_ms, uint64_t tag_mask, int grid, hipStream_t s,
+int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu);
+hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
+                                  const lbh_qarg& qa, int k, int has_since,
+                                  int64_t since_ms, uint64_t tag_mask, int grid, int nt, hipStream_t s,
                                   hipEvent_t ev0, hipEvent_t ev1);
-hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace& ws, int k, int has_since,
+hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
+                                   const lbh_qarg& qa, int k, int has_since,
                                    int64_t since_ms, uint64_t tag_mask, const lbh_cursor& cur, int grid,
                                    hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);

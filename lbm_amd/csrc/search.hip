@@ -22,6 +22,7 @@
 namespace {
 
 constexpr uint32_t PAD_ROW = 0xFFFFFFFFu;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct WaveSync {
     __device__ __forceinline__ void operator()() const { __builtin_amdgcn_wave_barrier(); }
@@ -113,11 +114,10 @@ __device__ __forceinline__ double exact_dot(const double* __restrict__ q, const 
 // leaving lane (g, c) with the complete score of tile row 4c + g.  Every row goes through the same
 // reduction tree, so bit-identical rows get bit-identical scores wherever they sit.
 // ------------------------------------------------------------------------------------------------
-template <bool SINCE, bool TAGS>
-__global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_index ix, const float* __restrict__ q32,
+template <bool SINCE, bool TAGS, bool NT>
+__global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_index ix, const double* __restrict__ qptr, lbh_qarg qa,
                                                                      int k, int64_t since_ms, uint64_t tag_mask,
-                                                                     uint64_t* __restrict__ lists,
-                                                                     int32_t* __restrict__ list_cnt,
+                                                                     uint64_t* __restrict__ cand,
                                                                      int32_t* __restrict__ flags) {
     __shared__ uint64_t wbuf[LBH_SCAN_WAVES][LBH_WCAP];
     __shared__ uint64_t mbuf[LBH_SCAN_WAVES * LBH_WCAP];
@@ -127,14 +127,18 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
     const int wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const float4 qf = reinterpret_cast<const float4*>(q32)[c];
-    const float4* __restrict__ E = reinterpret_cast<const float4*>(ix.emb32);
+    // query: device pointer (search_text: embedded on the GPU) or the kernel-argument copy (no H2D copy)
+    const double* __restrict__ qd = qptr ? qptr : qa.q;
+    const f32x4 qf = {(float)qd[4 * c], (float)qd[4 * c + 1], (float)qd[4 * c + 2], (float)qd[4 * c + 3]};
+    const f32x4* __restrict__ E = reinterpret_cast<const f32x4*>(ix.emb32);
     const int64_t n = ix.n;
     const int64_t n_tiles = (n + 63) >> 6;
     const int64_t n_vec = n * 16;
     uint64_t* buf = wbuf[wave];
 
     uint32_t thr = 0;  // ordered image of (k-th best so far - margin); 0 admits everything
+    // first compaction as soon as a threshold can exist (keeps the warm-up short on small corpora)
+    int trigger = 4 * k < 64 ? 64 : (4 * k > LBH_WCAP - 64 ? LBH_WCAP - 64 : 4 * k);
     int cnt = 0;
     bool dead = false;
 
@@ -163,13 +167,13 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
     for (int64_t tile = (int64_t)blockIdx.x * LBH_SCAN_WAVES + wave; tile < n_tiles && !dead;
          tile += (int64_t)gridDim.x * LBH_SCAN_WAVES) {
         const int64_t v0 = tile * 1024 + lane;
-        float4 x[16];
+        f32x4 x[16];
         if (v0 + 1024 - lane <= n_vec) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) x[j] = E[v0 + j * 64];
+            for (int j = 0; j < 16; ++j) x[j] = NT ? __builtin_nontemporal_load(&E[v0 + j * 64]) : E[v0 + j * 64];
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) x[j] = (v0 + j * 64 < n_vec) ? E[v0 + j * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < 16; ++j) x[j] = (v0 + j * 64 < n_vec) ? E[v0 + j * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         const int64_t myrow = tile * 64 + 4 * c + g;
         bool valid = myrow < n;
@@ -208,7 +212,10 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
             if (pass) buf[cnt + __popcll(m & lt_mask)] = ((uint64_t)o << 32) | (uint32_t)myrow;
             cnt += __popcll(m);
             __builtin_amdgcn_wave_barrier();
-            if (cnt > LBH_WCAP - 64) compact();
+            if (cnt >= trigger) {
+                compact();
+                trigger = cnt + 64 < LBH_WCAP - 64 + 1 ? cnt + 64 : LBH_WCAP - 64 + 1;
+            }
         }
     }
     if (!dead && cnt > 0) compact();
@@ -226,15 +233,12 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
     const int n2 = pow2_at_least(total, 64);
     for (int i = total + threadIdx.x; i < n2; i += LBH_SCAN_THREADS) mbuf[i] = 0;
     __syncthreads();
-    if (total == 0) {
-        if (threadIdx.x == 0) list_cnt[blockIdx.x] = 0;
-        return;
-    }
+    if (total == 0) return;
     sort_desc_u64(mbuf, n2, threadIdx.x, LBH_SCAN_THREADS, BlockSync());
     uint32_t bthr = 0;
     if (total >= k) bthr = lbh_ord32(lbh_unord32((uint32_t)(mbuf[k - 1] >> 32)) - LBH_MARGIN);
-    // survivors are a prefix of the sorted array
-    __shared__ int nsurv;
+    // survivors are a prefix of the sorted array; they go to one flat candidate array in HBM
+    __shared__ int nsurv, gbase;
     if (threadIdx.x == 0) nsurv = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < total; i += LBH_SCAN_THREADS) {
@@ -248,42 +252,74 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
         if (threadIdx.x == 0) atomicOr(&flags[0], 1);
         ns = LBH_LIST_CAP;
     }
-    for (int i = threadIdx.x; i < ns; i += LBH_SCAN_THREADS) lists[(size_t)blockIdx.x * LBH_LIST_CAP + i] = mbuf[i];
-    if (threadIdx.x == 0) list_cnt[blockIdx.x] = ns;
+    if (threadIdx.x == 0) gbase = atomicAdd(&flags[1], ns);
+    __syncthreads();
+    const int base = gbase;
+    for (int i = threadIdx.x; i < ns; i += LBH_SCAN_THREADS) cand[base + i] = mbuf[i];
 }
 
 // ------------------------------------------------------------------------------------------------
-// radix select over a set of lists in HBM: returns the `krem`-th largest value among the entries
-// for which val(l, i, &v) is true.  All threads of the block call it; result is block-uniform.
+// radix select over a flat array of E entries: returns the `krem`-th largest value among the
+// entries for which val(e, &v) is true.  All threads of the block call it; result is block-uniform.
 // ------------------------------------------------------------------------------------------------
 constexpr int SEL_THREADS = 1024;
 
 template <class F>
-__device__ uint64_t block_radix_select(int nlists, const int32_t* __restrict__ cnts, int nbytes, int64_t krem,
-                                       F val, int* hist, int64_t* sh_krem, int* sh_bin) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = SEL_THREADS / 64;
+__device__ uint64_t block_radix_select(int E, int nbytes, int64_t krem, F val, int* hist, int64_t* sh_krem,
+                                       int* sh_bin) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // value range first: digits are taken from (v - lo), so clustered values (scores share their high
+    // bits) spread over the bins instead of serialising every LDS atomic on one bin
+    __shared__ uint64_t sh_lo[SEL_THREADS / 64], sh_hi[SEL_THREADS / 64];
+    uint64_t lo = ~0ull, hi = 0;
+    for (int e = tid; e < E; e += SEL_THREADS) {
+        uint64_t v;
+        if (val(e, &v)) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if (lane == 0) { sh_lo[wave] = lo; sh_hi[wave] = hi; }
+    __syncthreads();
+    for (int w = 0; w < SEL_THREADS / 64; ++w) {
+        lo = sh_lo[w] < lo ? sh_lo[w] : lo;
+        hi = sh_hi[w] > hi ? sh_hi[w] : hi;
+    }
+    if (hi < lo) return 0;  // nothing in play
+    const uint64_t range = hi - lo;
+    nbytes = range ? (64 - __clzll(range) + 7) / 8 : 1;
     uint64_t prefix = 0, pmask = 0;
     for (int b = nbytes - 1; b >= 0; --b) {
         for (int t = tid; t < 256; t += SEL_THREADS) hist[t] = 0;
         __syncthreads();
-        for (int l = wave; l < nlists; l += nwaves) {
-            const int cn = cnts[l];
-            for (int i = lane; i < cn; i += 64) {
-                uint64_t v;
-                if (val(l, i, &v) && (v & pmask) == prefix) atomicAdd(&hist[(int)((v >> (8 * b)) & 255)], 1);
-            }
+        for (int e = tid; e < E; e += SEL_THREADS) {
+            uint64_t v;
+            if (val(e, &v) && ((v - lo) & pmask) == prefix) atomicAdd(&hist[(int)(((v - lo) >> (8 * b)) & 255)], 1);
         }
         __syncthreads();
-        if (tid == 0) {
-            int64_t rem = krem;
-            int bin = 255;
-            for (; bin > 0; --bin) {
-                const int h = hist[bin];
-                if (h >= rem) break;
-                rem -= h;
+        if (wave == 0) {  // wave-parallel search for the bin holding the krem-th largest value
+            const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const int s4 = h0 + h1 + h2 + h3;
+            int suf = s4;  // inclusive suffix sum over lanes (higher lanes = higher bins)
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_down(suf, off);
+                if (lane + off < 64) suf += t;
             }
-            *sh_krem = rem;
-            *sh_bin = bin;
+            const int64_t above = suf - s4;
+            if (above < krem && (int64_t)suf >= krem) {
+                int64_t rem = krem - above;
+                int bin;
+                if (h3 >= rem) bin = 4 * lane + 3;
+                else if (h3 + h2 >= rem) { bin = 4 * lane + 2; rem -= h3; }
+                else if (h3 + h2 + h1 >= rem) { bin = 4 * lane + 1; rem -= h3 + h2; }
+                else { bin = 4 * lane; rem -= h3 + h2 + h1; }
+                *sh_krem = rem;
+                *sh_bin = bin;
+            }
         }
         __syncthreads();
         krem = *sh_krem;
@@ -291,11 +327,11 @@ __device__ uint64_t block_radix_select(int nlists, const int32_t* __restrict__ c
         pmask |= 0xFFull << (8 * b);
         __syncthreads();
     }
-    return prefix;
+    return prefix + lo;
 }
 
-// shared tail of both final kernels: rows[0..M) -> exact scores -> exact sort -> result
-// `ebuf` is >= 3 * LBH_MCAP u64 of LDS: [0, MCAP) ord64 scores, then MCAP u32 rows.
+// shared tail of both final kernels: rows xr[0..M) (+ ord64 scores xo when have_scores) -> exact
+// scores -> exact sort -> result block
 __device__ void rerank_and_emit(uint64_t* xo, uint32_t* xr, int M, int k, const lbh_dev_index& ix,
                                 const double* qs, lbh_result* __restrict__ res, bool have_scores) {
     const int tid = threadIdx.x;
@@ -318,40 +354,32 @@ __device__ void rerank_and_emit(uint64_t* xo, uint32_t* xr, int M, int k, const 
 }
 
 // K4 (fast path): global fp32 threshold, candidate cut, exact fp64 re-rank.
-__global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index ix, const double* __restrict__ q64,
-                                                                   int k, int nlists,
-                                                                   const uint64_t* __restrict__ lists,
-                                                                   const int32_t* __restrict__ list_cnt,
-                                                                   const int32_t* __restrict__ flags,
+__global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index ix, const double* __restrict__ qptr,
+                                                                   lbh_qarg qa, int k,
+                                                                   const uint64_t* __restrict__ cand,
+                                                                   int32_t* __restrict__ flags,
                                                                    lbh_result* __restrict__ res) {
     __shared__ uint64_t sbuf[2 * LBH_MCAP];      // 32 KB: entries, later (ord64 | rows)
-    __shared__ int pref[LBH_MAX_BLOCKS + 1];
     __shared__ double qs[64];
     __shared__ int hist[256];
     __shared__ int64_t sh_krem;
     __shared__ int sh_bin, sh_cnt;
     const int tid = threadIdx.x;
 
-    if (flags[0]) {
+    const int overflowed = flags[0];
+    const int E = flags[1];
+    if (tid < 64) qs[tid] = qptr ? qptr[tid] : qa.q[tid];
+    if (tid == 0) sh_cnt = 0;
+    __syncthreads();
+    if (tid < 4) flags[tid] = 0;  // leave the counters zeroed for the next launch (no memset node needed)
+    if (overflowed) {
         if (tid == 0) { res->count = 0; res->overflow = 1; res->candidates = 0; }
         return;
     }
-    if (tid < 64) qs[tid] = q64[tid];
-    if (tid == 0) {  // nlists <= 2048: a serial prefix sum is ~2 us; keeps the kernel simple
-        int a = 0;
-        for (int l = 0; l < nlists; ++l) { pref[l] = a; a += list_cnt[l]; }
-        pref[nlists] = a;
-        sh_cnt = 0;
-    }
-    __syncthreads();
-    const int E = pref[nlists];
     int M = 0;
     uint32_t thr = 0;
     if (E <= 2 * LBH_MCAP) {
-        for (int l = tid; l < nlists; l += SEL_THREADS) {
-            const int c0 = pref[l], cn = pref[l + 1] - c0;
-            for (int i = 0; i < cn; ++i) sbuf[c0 + i] = lists[(size_t)l * LBH_LIST_CAP + i];
-        }
+        for (int e = tid; e < E; e += SEL_THREADS) sbuf[e] = cand[e];
         const int n2 = pow2_at_least(E, 2);
         for (int i = E + tid; i < n2; i += SEL_THREADS) sbuf[i] = 0;
         __syncthreads();
@@ -366,22 +394,18 @@ __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index 
         M = sh_cnt;
     } else {
         if (E >= k) {
-            auto val = [&](int l, int i, uint64_t* v) {
-                *v = lists[(size_t)l * LBH_LIST_CAP + i] >> 32;
+            auto val = [&](int e, uint64_t* v) {
+                *v = cand[e] >> 32;
                 return true;
             };
-            const uint32_t kth = (uint32_t)block_radix_select(nlists, list_cnt, 4, k, val, hist, &sh_krem, &sh_bin);
+            const uint32_t kth = (uint32_t)block_radix_select(E, 4, k, val, hist, &sh_krem, &sh_bin);
             thr = lbh_ord32(lbh_unord32(kth) - LBH_MARGIN);
         }
-        const int lane = tid & 63, wave = tid >> 6;
-        for (int l = wave; l < nlists; l += SEL_THREADS / 64) {
-            const int cn = list_cnt[l];
-            for (int i = lane; i < cn; i += 64) {
-                const uint64_t e = lists[(size_t)l * LBH_LIST_CAP + i];
-                if ((uint32_t)(e >> 32) >= thr) {
-                    const int pos = atomicAdd(&sh_cnt, 1);
-                    if (pos < 2 * LBH_MCAP) sbuf[pos] = e;
-                }
+        for (int e = tid; e < E; e += SEL_THREADS) {
+            const uint64_t v = cand[e];
+            if ((uint32_t)(v >> 32) >= thr) {
+                const int pos = atomicAdd(&sh_cnt, 1);
+                if (pos < 2 * LBH_MCAP) sbuf[pos] = v;
             }
         }
         __syncthreads();
@@ -409,18 +433,18 @@ __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index 
 // Per-wave top-k under the full (score desc, key asc) order, so ties never overflow a buffer.
 // ------------------------------------------------------------------------------------------------
 template <bool SINCE, bool TAGS>
-__global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_exact_kernel(lbh_dev_index ix, const double* __restrict__ q64,
+__global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_exact_kernel(lbh_dev_index ix, const double* __restrict__ qptr, lbh_qarg qa,
                                                                        int k, int64_t since_ms, uint64_t tag_mask,
                                                                        lbh_cursor cur,
-                                                                       uint64_t* __restrict__ xl_ord,
-                                                                       uint32_t* __restrict__ xl_row,
-                                                                       int32_t* __restrict__ xl_cnt) {
+                                                                       uint64_t* __restrict__ xc_ord,
+                                                                       uint32_t* __restrict__ xc_row,
+                                                                       int32_t* __restrict__ flags) {
     __shared__ uint64_t wo[LBH_SCAN_WAVES][LBH_WCAP];
     __shared__ uint32_t wr[LBH_SCAN_WAVES][LBH_WCAP];
     __shared__ double qs[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    if (threadIdx.x < 64) qs[threadIdx.x] = q64[threadIdx.x];
+    if (threadIdx.x < 64) qs[threadIdx.x] = qptr ? qptr[threadIdx.x] : qa.q[threadIdx.x];
     __syncthreads();
     uint64_t* bo = wo[wave];
     uint32_t* br = wr[wave];
@@ -479,70 +503,67 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_exact_kernel(lbh_dev_in
         }
     }
     if (cnt > 0) compact();
-    const size_t li = (size_t)blockIdx.x * LBH_SCAN_WAVES + wave;
+    int base = 0;
+    if (lane == 0 && cnt > 0) base = atomicAdd(&flags[2], cnt);
+    base = __shfl(base, 0);
     for (int i = lane; i < cnt; i += 64) {
-        xl_ord[li * LBH_MAX_PAGE + i] = bo[i];
-        xl_row[li * LBH_MAX_PAGE + i] = br[i];
+        xc_ord[base + i] = bo[i];
+        xc_row[base + i] = br[i];
     }
-    if (lane == 0) xl_cnt[li] = cnt;
 }
 
-__global__ __launch_bounds__(SEL_THREADS) void select_exact_kernel(lbh_dev_index ix, int k, int nlists,
-                                                                    const uint64_t* __restrict__ xl_ord,
-                                                                    const uint32_t* __restrict__ xl_row,
-                                                                    const int32_t* __restrict__ xl_cnt,
+__global__ __launch_bounds__(SEL_THREADS) void select_exact_kernel(lbh_dev_index ix, int k,
+                                                                    const uint64_t* __restrict__ xc_ord,
+                                                                    const uint32_t* __restrict__ xc_row,
+                                                                    int32_t* __restrict__ flags,
                                                                     lbh_result* __restrict__ res) {
     __shared__ uint64_t sbuf[2 * LBH_MCAP];
     __shared__ int hist[256];
     __shared__ int64_t sh_krem;
-    __shared__ int sh_bin, sh_cnt, sh_gt, sh_eq, sh_total;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = SEL_THREADS / 64;
-    if (tid == 0) { sh_cnt = 0; sh_gt = 0; sh_eq = 0; sh_total = 0; }
+    __shared__ int sh_bin, sh_cnt, sh_gt, sh_eq;
+    const int tid = threadIdx.x;
+    if (tid == 0) { sh_cnt = 0; sh_gt = 0; sh_eq = 0; }
+    const int E = flags[2];
     __syncthreads();
-    for (int l = tid; l < nlists; l += SEL_THREADS) atomicAdd(&sh_total, xl_cnt[l]);
-    __syncthreads();
-    const int E = sh_total;
+    if (tid < 4) flags[tid] = 0;
     uint64_t* xo = sbuf;
     uint32_t* xr = reinterpret_cast<uint32_t*>(sbuf + LBH_MCAP);
 
-    uint64_t kth = 0;       // admit everything unless there are more than k entries
+    uint64_t kth = 0;       // admit everything unless there are more entries than the final sort holds
     uint64_t key0_cut = ~0ull;
     bool use_key_cut = false;
     if (E > LBH_MCAP) {
-        auto val = [&](int l, int i, uint64_t* v) { *v = xl_ord[(size_t)l * LBH_MAX_PAGE + i]; return true; };
-        kth = block_radix_select(nlists, xl_cnt, 8, k, val, hist, &sh_krem, &sh_bin);
-        for (int l = wave; l < nlists; l += nwaves) {
-            const int cn = xl_cnt[l];
-            for (int i = lane; i < cn; i += 64) {
-                const uint64_t o = xl_ord[(size_t)l * LBH_MAX_PAGE + i];
-                if (o > kth) atomicAdd(&sh_gt, 1);
-                else if (o == kth) atomicAdd(&sh_eq, 1);
-            }
+        auto val = [&](int e, uint64_t* v) { *v = xc_ord[e]; return true; };
+        kth = block_radix_select(E, 8, k, val, hist, &sh_krem, &sh_bin);
+        int gt = 0, eq = 0;
+        for (int e = tid; e < E; e += SEL_THREADS) {
+            const uint64_t o = xc_ord[e];
+            gt += o > kth;
+            eq += o == kth;
         }
+        if (gt) atomicAdd(&sh_gt, gt);
+        if (eq) atomicAdd(&sh_eq, eq);
         __syncthreads();
         if (sh_gt + sh_eq > LBH_MCAP) {
             // mass tie on the k-th score: cut the tie group by the first key word (ascending)
             const int64_t need = k - sh_gt;
-            auto kval = [&](int l, int i, uint64_t* v) {
-                if (xl_ord[(size_t)l * LBH_MAX_PAGE + i] != kth) return false;
-                *v = ~ix.keys[(size_t)xl_row[(size_t)l * LBH_MAX_PAGE + i] * 4];
+            auto kval = [&](int e, uint64_t* v) {
+                if (xc_ord[e] != kth) return false;
+                *v = ~ix.keys[(size_t)xc_row[e] * 4];
                 return true;
             };
-            key0_cut = ~block_radix_select(nlists, xl_cnt, 8, need, kval, hist, &sh_krem, &sh_bin);
+            key0_cut = ~block_radix_select(E, 8, need, kval, hist, &sh_krem, &sh_bin);
             use_key_cut = true;
         }
     }
-    for (int l = wave; l < nlists; l += nwaves) {
-        const int cn = xl_cnt[l];
-        for (int i = lane; i < cn; i += 64) {
-            const uint64_t o = xl_ord[(size_t)l * LBH_MAX_PAGE + i];
-            const uint32_t r = xl_row[(size_t)l * LBH_MAX_PAGE + i];
-            bool in = o >= kth;
-            if (in && use_key_cut && o == kth) in = ix.keys[(size_t)r * 4] <= key0_cut;
-            if (in) {
-                const int pos = atomicAdd(&sh_cnt, 1);
-                if (pos < LBH_MCAP) { xo[pos] = o; xr[pos] = r; }
-            }
+    for (int e = tid; e < E; e += SEL_THREADS) {
+        const uint64_t o = xc_ord[e];
+        const uint32_t r = xc_row[e];
+        bool in = o >= kth;
+        if (in && use_key_cut && o == kth) in = ix.keys[(size_t)r * 4] <= key0_cut;
+        if (in) {
+            const int pos = atomicAdd(&sh_cnt, 1);
+            if (pos < LBH_MCAP) { xo[pos] = o; xr[pos] = r; }
         }
     }
     __syncthreads();
@@ -556,53 +577,58 @@ __global__ __launch_bounds__(SEL_THREADS) void select_exact_kernel(lbh_dev_index
 
 }  // namespace
 
-int lbh_scan_grid(int64_t n_rows, int n_cu) {
+int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu) {
     const int64_t tiles = (n_rows + 63) / 64;
     int64_t blocks = (tiles + LBH_SCAN_WAVES - 1) / LBH_SCAN_WAVES;
-    const int64_t cap = (int64_t)n_cu * 4 < LBH_MAX_BLOCKS ? (int64_t)n_cu * 4 : LBH_MAX_BLOCKS;
+    const int64_t cap = (int64_t)n_cu * blocks_per_cu < LBH_MAX_BLOCKS ? (int64_t)n_cu * blocks_per_cu : LBH_MAX_BLOCKS;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
 
-hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const lbh_workspace& ws, int k, int has_since,
-                                  int64_t since_ms, uint64_t tag_mask, int grid, hipStream_t s, hipEvent_t ev0,
-                                  hipEvent_t ev1) {
-    hipError_t e = hipMemsetAsync(ws.flags, 0, 16, s);
-    if (e != hipSuccess) return e;
-    if (ev0) hipEventRecord(ev0, s);
+hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
+                                  const lbh_qarg& qa, int k, int has_since,
+                                  int64_t since_ms, uint64_t tag_mask, int grid, int nt, hipStream_t s,
+                                  hipEvent_t ev0, hipEvent_t ev1) {
+    hipError_t e;
+    if (ev0) (void)hipEventRecord(ev0, s);
     const dim3 g(grid), b(LBH_SCAN_THREADS);
-    if (has_since && tag_mask)
-        scan_f32_kernel<true, true><<<g, b, 0, s>>>(ix, ws.q32, k, since_ms, tag_mask, ws.lists, ws.list_cnt, ws.flags);
-    else if (has_since)
-        scan_f32_kernel<true, false><<<g, b, 0, s>>>(ix, ws.q32, k, since_ms, tag_mask, ws.lists, ws.list_cnt, ws.flags);
-    else if (tag_mask)
-        scan_f32_kernel<false, true><<<g, b, 0, s>>>(ix, ws.q32, k, since_ms, tag_mask, ws.lists, ws.list_cnt, ws.flags);
-    else
-        scan_f32_kernel<false, false><<<g, b, 0, s>>>(ix, ws.q32, k, since_ms, tag_mask, ws.lists, ws.list_cnt, ws.flags);
-    if (ev1) hipEventRecord(ev1, s);
+#define LBH_SCAN_ARGS ix, qptr, qa, k, since_ms, tag_mask, ws.cand, ws.flags
+    if (nt) {
+        if (has_since && tag_mask) scan_f32_kernel<true, true, true><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
+        else if (has_since) scan_f32_kernel<true, false, true><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
+        else if (tag_mask) scan_f32_kernel<false, true, true><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
+        else scan_f32_kernel<false, false, true><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
+    } else {
+        if (has_since && tag_mask) scan_f32_kernel<true, true, false><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
+        else if (has_since) scan_f32_kernel<true, false, false><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
+        else if (tag_mask) scan_f32_kernel<false, true, false><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
+        else scan_f32_kernel<false, false, false><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
+    }
+#undef LBH_SCAN_ARGS
+    if (ev1) (void)hipEventRecord(ev1, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, ws.q64, k, grid, ws.lists, ws.list_cnt, ws.flags, ws.result);
+    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, qptr, qa, k, ws.cand, ws.flags, ws.result_dev);
     return hipGetLastError();
 }
 
-hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace& ws, int k, int has_since,
+hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
+                                   const lbh_qarg& qa, int k, int has_since,
                                    int64_t since_ms, uint64_t tag_mask, const lbh_cursor& cur, int grid,
                                    hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    if (ev0) hipEventRecord(ev0, s);
+    hipError_t e;
+    if (ev0) (void)hipEventRecord(ev0, s);
     const dim3 g(grid), b(LBH_SCAN_THREADS);
-    if (has_since && tag_mask)
-        scan_exact_kernel<true, true><<<g, b, 0, s>>>(ix, ws.q64, k, since_ms, tag_mask, cur, ws.xlists_ord, ws.xlists_row, ws.xlist_cnt);
-    else if (has_since)
-        scan_exact_kernel<true, false><<<g, b, 0, s>>>(ix, ws.q64, k, since_ms, tag_mask, cur, ws.xlists_ord, ws.xlists_row, ws.xlist_cnt);
-    else if (tag_mask)
-        scan_exact_kernel<false, true><<<g, b, 0, s>>>(ix, ws.q64, k, since_ms, tag_mask, cur, ws.xlists_ord, ws.xlists_row, ws.xlist_cnt);
-    else
-        scan_exact_kernel<false, false><<<g, b, 0, s>>>(ix, ws.q64, k, since_ms, tag_mask, cur, ws.xlists_ord, ws.xlists_row, ws.xlist_cnt);
-    if (ev1) hipEventRecord(ev1, s);
-    hipError_t e = hipGetLastError();
+#define LBH_XSCAN_ARGS ix, qptr, qa, k, since_ms, tag_mask, cur, ws.xcand_ord, ws.xcand_row, ws.flags
+    if (has_since && tag_mask) scan_exact_kernel<true, true><<<g, b, 0, s>>>(LBH_XSCAN_ARGS);
+    else if (has_since) scan_exact_kernel<true, false><<<g, b, 0, s>>>(LBH_XSCAN_ARGS);
+    else if (tag_mask) scan_exact_kernel<false, true><<<g, b, 0, s>>>(LBH_XSCAN_ARGS);
+    else scan_exact_kernel<false, false><<<g, b, 0, s>>>(LBH_XSCAN_ARGS);
+#undef LBH_XSCAN_ARGS
+    if (ev1) (void)hipEventRecord(ev1, s);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
-    select_exact_kernel<<<1, SEL_THREADS, 0, s>>>(ix, k, grid * LBH_SCAN_WAVES, ws.xlists_ord, ws.xlists_row, ws.xlist_cnt, ws.result);
+    select_exact_kernel<<<1, SEL_THREADS, 0, s>>>(ix, k, ws.xcand_ord, ws.xcand_row, ws.flags, ws.result_dev);
     return hipGetLastError();
 }
