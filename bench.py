@@ -165,6 +165,15 @@ def main():
 
     if rank == 0:
         bytes_per_row = 256 + (8 if args.since != "none" else 0)
+        traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/*pmc_scan.json), scaled to this row count
+        try:
+            import glob
+            pmc = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_scan.json")))
+            if pmc and args.since == "none":
+                with open(pmc[-1]) as f:
+                    traffic = json.load(f)["scan_f32_kernel"]["hbm_bytes_per_row"] * live
+        except Exception:
+            traffic = None
         avg_scan_s = scan_ms / 1e3 / max(n_timed, 1)
         achieved = live * bytes_per_row / avg_scan_s / 1e9 if avg_scan_s > 0 else 0.0
         out = {
@@ -181,7 +190,8 @@ def main():
                        "parallelism": f"claim-sharded x{world}, all-gather top-k merge" if world > 1 else "single GPU"},
             "latency_ms": {"p50": float(np.percentile(lat, 50) * 1e3), "p99": float(np.percentile(lat, 99) * 1e3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "scan_f32_kernel",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": live * bytes_per_row, "kernel": "scan_f32_kernel",
                          "bytes_per_claim": bytes_per_row, "avg_kernel_us": avg_scan_s * 1e6},
             "vectorise": {"claims_per_s_incl_h2d": args.claims / t_add if t_add > 0 else None,
                           "host_text_generation_s": t_gen},
