@@ -75,6 +75,6 @@ class ShardedSearcher:
         t = torch.from_numpy(local)
         if self.device is not None:
             t = t.to(self.device, non_blocking=True)
-        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t, group=self.group)
-        return merge_gathered(out.cpu().numpy(), k)
+        out = torch.empty((self.world * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)  # rank-major concatenation
+        return merge_gathered(out.cpu().numpy().reshape(self.world, t.shape[0], t.shape[1]), k)

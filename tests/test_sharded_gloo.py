@@ -1,0 +1,91 @@
+"""N > 1 path on CPU: two gloo ranks each own a shard, the all-gather merge must return exactly the
+single-corpus answer (ids, fp64 score bits, order).  The rank-local search is played by the CPU oracle
+here (test infrastructure); on the GPU box the same ShardedSearcher wraps Index.search_shard."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, out_q):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from lbm_amd import synth
+    from lbm_amd.sharded import ShardedSearcher
+    from oracle import lb_oracle as orc
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ch = synth.make_chunk(0, n, seed=31, dup_frac=0.02)
+    emb = orc.embed_batch_packed(ch.blob, ch.offsets)
+    mine = np.arange(rank, n, world)            # claims dealt round-robin: global id = local * world + rank
+    keys_hex = ch.hashes()
+    my_keys = [keys_hex[i] for i in mine]
+    retr = ch.retracted.astype(np.uint8)
+
+    def local_search(q, k, since_ms, tag_mask):
+        idx, sc = orc.compile_arrays(emb[mine], ch.created_ms[mine], retr[mine], my_keys, q, k,
+                                     None if since_ms is None else since_ms, ch.tagmask[mine], tag_mask)
+        return idx.astype(np.uint64), sc, ch.keys[mine][idx]
+
+    s = ShardedSearcher(local_search, rank, world)
+    results = []
+    for qtext in synth.make_queries(5, seed=3) + [ch.text(10), ""]:
+        q = orc.embed_array(qtext)
+        for k, since in ((8, None), (64, int(ch.created_ms[n // 2])), (3, None)):
+            gids, sc, kw = s.search(q, k, since, 0)
+            want_idx, want_sc = orc.compile_arrays(emb, ch.created_ms, retr, keys_hex, q, k, since)
+            results.append((gids.tolist() == want_idx.tolist(), sc.tobytes() == want_sc.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+    out_q.put((rank, results))
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_allgather_merge_equals_single_corpus():
+    world, n = 2, 3000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=90) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, results in got:
+        assert len(results) == 21
+        assert all(a and b for a, b in results), (rank, results)
+
+
+def test_merge_orders_ties_by_key_and_handles_short_lists():
+    from lbm_amd.sharded import merge_gathered, pack_local
+    k = 4
+    keys = np.zeros((3, 32), dtype=np.uint8)
+    keys[0, 0], keys[1, 0], keys[2, 0] = 9, 1, 5
+    a = pack_local(np.array([0.5, 0.5, 0.25]), np.array([10, 11, 12], dtype=np.uint64), keys, k)
+    keys_b = np.zeros((1, 32), dtype=np.uint8)
+    keys_b[0, 0] = 3
+    b = pack_local(np.array([0.5]), np.array([20], dtype=np.uint64), keys_b, k)
+    c = pack_local(np.zeros(0), np.zeros(0, dtype=np.uint64), np.zeros((0, 32), dtype=np.uint8), k)
+    ids, sc, kw = merge_gathered(np.stack([a, b, c]), k)
+    assert ids.tolist() == [11, 20, 10, 12] and sc.tolist() == [0.5, 0.5, 0.5, 0.25]
+    ids, sc, _ = merge_gathered(np.stack([c, c]), k)
+    assert ids.shape == (0,)
+    # -0.0 and +0.0 tie exactly like Python's (-s, h) sort key
+    z = pack_local(np.array([-0.0]), np.array([1], dtype=np.uint64), keys[:1], k)
+    y = pack_local(np.array([0.0]), np.array([2], dtype=np.uint64), keys[1:2], k)
+    ids, _, _ = merge_gathered(np.stack([z, y]), k)
+    assert ids.tolist() == [2, 1]
