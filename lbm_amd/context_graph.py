@@ -372,6 +372,10 @@ class ContextGraph:
         ``tags`` (extension, default off): keep only claims carrying at least one of these tags.
         """
         chosen, _ = self._rank(query, top_k, since_ms, tags)
+        return self._format(query, chosen), chosen
+
+    def _format(self, query: str, chosen: List[str]) -> str:
+        """lb/context_graph.py:122-133."""
         lines = ["Context slice", f"Query: {query}", ""]
         for i, h in enumerate(chosen, 1):
             c = self.claims[h]
@@ -380,7 +384,7 @@ class ContextGraph:
                 lines.append(f"{i}. {c.text}  [tags: {tag_str}]")
             else:
                 lines.append(f"{i}. {c.text}")
-        return "\n".join(lines).strip() + "\n", chosen
+        return "\n".join(lines).strip() + "\n"
 
     def compile_scored(self, query: str, *, top_k: int = 8, since_ms: Optional[int] = None,
                        tags: Optional[Sequence[str]] = None, stats: Optional[_hip.Stats] = None
@@ -388,15 +392,14 @@ class ContextGraph:
         """Ranking only: (claim hashes, fp64 scores) in the reference's order."""
         return self._rank(query, top_k, since_ms, tags, stats)
 
-    def _rank(self, query, top_k, since_ms, tags, stats=None) -> Tuple[List[str], List[float]]:
-        self._sync()
-        k = max(0, int(top_k))  # :121
+    def _filters(self, since_ms, tags) -> Tuple[int, int, bool]:
+        """(since for the C ABI, tag mask, provably-empty flag)."""
         if since_ms is None:
             since = _hip.SINCE_NONE
         else:
             since = since_ms if isinstance(since_ms, int) else int(np.ceil(since_ms))
             if since > _hip.INT64_MAX:
-                return [], []  # created_ms < since_ms holds for every storable timestamp
+                return 0, 0, True  # created_ms < since_ms holds for every storable timestamp
             since = max(since, _hip.SINCE_NONE)
         tag_mask = 0
         if tags is not None:
@@ -407,12 +410,38 @@ class ContextGraph:
                 elif self._tag_overflow:
                     raise NotImplementedError("tag filter: this graph uses more than 64 distinct tags")
             if tag_mask == 0:
-                return [], []  # no claim carries any of the requested tags
+                return since, 0, True  # no claim carries any of the requested tags
+        return since, tag_mask, False
+
+    def _rank(self, query, top_k, since_ms, tags, stats=None) -> Tuple[List[str], List[float]]:
+        self._sync()
+        k = max(0, int(top_k))  # :121
+        since, tag_mask, empty = self._filters(since_ms, tags)
+        if empty:
+            return [], []
         index = self._index  # opens the HIP backend even for an empty graph: no silent CPU path
         if k == 0 or not self._id_of:
             return [], []
         ids, scores, _ = index.search_text(query, k, since, tag_mask, stats)
         return [self._hash_of[i] for i in ids.tolist()], scores.tolist()
+
+    def compile_many(self, queries: Sequence[str], *, top_k: int = 8, since_ms: Optional[int] = None,
+                     tags: Optional[Sequence[str]] = None) -> List[Tuple[str, List[str]]]:
+        """Batched ``compile`` (extension; the reference has no batched entry): the queries are embedded
+        in one K1 launch and ranked in one pass over the claim matrix on the matrix cores (K3).  Each
+        element equals ``compile(q, top_k=..., since_ms=..., tags=...)`` exactly."""
+        self._sync()
+        k = max(0, int(top_k))
+        since, tag_mask, empty = self._filters(since_ms, tags)
+        index = self._index
+        ranked: List[List[str]]
+        if empty or k == 0 or not self._id_of or not queries:
+            ranked = [[] for _ in queries]
+        else:
+            qv = _hip.embed_batch(list(queries))
+            ids, _, cnt = index.search(qv, k, since, tag_mask)
+            ranked = [[self._hash_of[i] for i in ids[j, : int(cnt[j])].tolist()] for j in range(len(queries))]
+        return [(self._format(q, chosen), chosen) for q, chosen in zip(queries, ranked)]
 
     def snapshot(self) -> Dict[str, Any]:
         return {"claims": {h: c.to_dict() for h, c in self.claims.items()}}

@@ -271,6 +271,17 @@ int search_loaded(lbh_index* ix, int64_t k, int64_t since_ms, uint64_t tag_mask,
     return LBH_OK;
 }
 
+int ensure_batched_ws(lbh_index* ix) {
+    lbh_workspace& w = ix->ws;
+    if (w.bq_qmat) return LBH_OK;
+    HIP_TRY(hipMalloc((void**)&w.bq_qmat, (size_t)LBH_BQ_MAXQ * 512));
+    HIP_TRY(hipMalloc((void**)&w.bq_cand, (size_t)LBH_BQ_MAXQ * LBH_BQ_PERQ * 8));
+    HIP_TRY(hipMalloc((void**)&w.bq_total, (size_t)LBH_BQ_MAXQ * 4));
+    HIP_TRY(hipHostMalloc((void**)&w.bq_result_host, sizeof(lbh_result) * LBH_BQ_MAXQ, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void**)&w.bq_result_dev, w.bq_result_host, 0));
+    return LBH_OK;
+}
+
 int load_query(lbh_index* ix, const double* q) {
     memcpy(ix->qarg.q, q, sizeof ix->qarg.q);  // travels to the GPU inside the kernel-argument segment
     ix->qptr = nullptr;
@@ -424,10 +435,11 @@ int lbh_index_destroy(lbh_index* ix) {
     hipStreamSynchronize(ix->ctx->stream);
     lbh_workspace& w = ix->ws;
     void* dev[] = {ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, w.q64, w.cand, w.xcand_ord, w.xcand_row,
-                   w.flags};
+                   w.flags, w.bq_qmat, w.bq_cand, w.bq_total};
     for (void* p : dev)
         if (p) hipFree(p);
     if (w.result_host) hipHostFree(w.result_host);
+    if (w.bq_result_host) hipHostFree(w.bq_result_host);
     if (ix->staging) hipHostFree(ix->staging);
     delete ix;
     return LBH_OK;
@@ -588,7 +600,49 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
     HIP_TRY(hipSetDevice(ix->ctx->device));
     lbh_stats total;
     memset(&total, 0, sizeof total);
+    const bool timing = stats && stats->want_timing;
+    const int64_t keff = std::min<int64_t>(k, ix->n);
+    std::vector<char> done((size_t)nq, 0);
+    // K3: three or more queries with a small k share ONE pass over the claim matrix on the matrix
+    // cores (256 queries per launch).  A query whose candidate set could not be bounded there is
+    // re-run below on the single-query path, so results never depend on which path served them.
+    if (nq >= 3 && keff >= 1 && keff <= LBH_BQ_KMAX && ix->n > 0) {
+        int rc = ensure_batched_ws(ix);
+        if (rc) return rc;
+        lbh_ctx* c = ix->ctx;
+        hipStream_t s = c->stream;
+        const lbh_dev_index dv = dev_view(ix);
+        const int has_since = since_ms != LBH_SINCE_NONE;
+        for (int64_t q0 = 0; q0 < nq; q0 += LBH_BQ_MAXQ) {
+            const int nb = (int)std::min<int64_t>(LBH_BQ_MAXQ, nq - q0);
+            HIP_TRY(hipMemcpyAsync(ix->ws.bq_qmat, q_f64 + q0 * 64, (size_t)nb * 512, hipMemcpyHostToDevice, s));
+            HIP_TRY(lbh_launch_search_batched(dv, ix->ws, nb, (int)keff, has_since, since_ms, tag_mask, c->n_cu, s,
+                                              timing ? c->ev[0] : nullptr, timing ? c->ev[1] : nullptr));
+            HIP_TRY(hipStreamSynchronize(s));
+            total.scan_launches += 1;
+            total.rows_scanned += ix->n;
+            if (timing) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) total.scan_ms += ms;
+            }
+            for (int i = 0; i < nb; ++i) {
+                const lbh_result* r = ix->ws.bq_result_host + i;
+                if (r->overflow) continue;  // served by the single-query path below
+                const int64_t q = q0 + i;
+                for (int j = 0; j < r->count; ++j) {
+                    out_ids[q * k + j] = ix->id_of_row[r->rows[j]];
+                    out_scores[q * k + j] = r->scores[j];
+                }
+                out_counts[q] = r->count;
+                total.candidates += r->candidates;
+                done[(size_t)q] = 1;
+            }
+        }
+        total.path = 2;
+        total.bytes_per_row = 256 + (has_since ? 8 : 0) + (tag_mask ? 8 : 0);
+    }
     for (int64_t q = 0; q < nq; ++q) {
+        if (done[(size_t)q]) continue;
         int rc = load_query(ix, q_f64 + q * 64);
         if (rc) return rc;
         lbh_stats st;
@@ -598,9 +652,13 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
                            stats ? &st : nullptr);
         if (rc) return rc;
         if (stats) {
-            total.path = st.path;
+            if (total.path != 2) {
+                total.path = st.path;
+                total.bytes_per_row = st.bytes_per_row;
+            } else {
+                total.fallbacks += 1;
+            }
             total.rows_scanned += st.rows_scanned;
-            total.bytes_per_row = st.bytes_per_row;
             total.candidates += st.candidates;
             total.scan_launches += st.scan_launches;
             total.fallbacks += st.fallbacks;

@@ -12,6 +12,9 @@
 #define LBH_WCAP 256                            // per-wave candidate buffer (entries) in LDS
 #define LBH_LIST_CAP 256                        // per-block candidate list written to HBM
 #define LBH_MCAP 2048                           // max rows the single-block final stage sorts exactly
+#define LBH_BQ_MAXQ 256                         // queries per batched (MFMA) launch
+#define LBH_BQ_PERQ 8192                        // candidate slots per query of a batched launch
+#define LBH_BQ_KMAX 16                          // largest top_k the batched path serves
 #define LBH_MAX_BLOCKS 2048                     // max scan grid (lists in the workspace)
 
 // fp32 scan vs reference fp64 score: rigorous bound on |s32 - s64| is < 4e-6 for unit 64-vectors
@@ -76,6 +79,12 @@ struct lbh_workspace {
     uint64_t* xcand_ord;      // flat, LBH_MAX_BLOCKS*4 x LBH_MAX_PAGE entries: ord64(score)     exact path
     uint32_t* xcand_row;      // same shape: row
     int32_t* flags;           // [0] overflow, [1] entries in cand, [2] entries in xcand (zeroed per launch)
+    // batched (K3) workspace, allocated on first use
+    double* bq_qmat;          // 256 x 64 fp64 query matrix
+    uint64_t* bq_cand;        // 256 x LBH_BQ_PERQ flat candidate lists, one per query
+    int32_t* bq_total;        // 256 counters
+    lbh_result* bq_result_host;  // 256 results, pinned + device-mapped
+    lbh_result* bq_result_dev;
     lbh_result* result_host;  // pinned, device-mapped host memory: the final kernel writes it directly
     lbh_result* result_dev;   // device-side address of result_host
 };
@@ -98,3 +107,6 @@ hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace&
                                    const lbh_qarg& qa, int k, int has_since,
                                    int64_t since_ms, uint64_t tag_mask, const lbh_cursor& cur, int grid,
                                    hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspace& ws, int nq, int k, int has_since,
+                                     int64_t since_ms, uint64_t tag_mask, int n_cu, hipStream_t s, hipEvent_t ev0,
+                                     hipEvent_t ev1);

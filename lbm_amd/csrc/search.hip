@@ -353,29 +353,17 @@ __device__ void rerank_and_emit(uint64_t* xo, uint32_t* xr, int M, int k, const 
     if (tid == 0) { res->count = cnt; res->overflow = 0; res->candidates = M; }
 }
 
-// K4 (fast path): global fp32 threshold, candidate cut, exact fp64 re-rank.
-__global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index ix, const double* __restrict__ qptr,
-                                                                   lbh_qarg qa, int k,
-                                                                   const uint64_t* __restrict__ cand,
-                                                                   int32_t* __restrict__ flags,
-                                                                   lbh_result* __restrict__ res) {
+// K4 body: global fp32 threshold over E flat candidates, candidate cut, exact fp64 re-rank.
+// `qs` (64 doubles in LDS) must be filled and a barrier passed before the call.
+__device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int k, const uint64_t* __restrict__ cand,
+                                 int E, lbh_result* __restrict__ res) {
     __shared__ uint64_t sbuf[2 * LBH_MCAP];      // 32 KB: entries, later (ord64 | rows)
-    __shared__ double qs[64];
     __shared__ int hist[256];
     __shared__ int64_t sh_krem;
     __shared__ int sh_bin, sh_cnt;
     const int tid = threadIdx.x;
-
-    const int overflowed = flags[0];
-    const int E = flags[1];
-    if (tid < 64) qs[tid] = qptr ? qptr[tid] : qa.q[tid];
     if (tid == 0) sh_cnt = 0;
     __syncthreads();
-    if (tid < 4) flags[tid] = 0;  // leave the counters zeroed for the next launch (no memset node needed)
-    if (overflowed) {
-        if (tid == 0) { res->count = 0; res->overflow = 1; res->candidates = 0; }
-        return;
-    }
     int M = 0;
     uint32_t thr = 0;
     if (E <= 2 * LBH_MCAP) {
@@ -426,6 +414,201 @@ __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index 
     if (tid + SEL_THREADS < M) xr[tid + SEL_THREADS] = myrows[1];
     __syncthreads();
     rerank_and_emit(xo, xr, M, k, ix, qs, res, false);
+}
+
+// K4 (fast path, one query): one block.
+__global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index ix, const double* __restrict__ qptr,
+                                                                   lbh_qarg qa, int k,
+                                                                   const uint64_t* __restrict__ cand,
+                                                                   int32_t* __restrict__ flags,
+                                                                   lbh_result* __restrict__ res) {
+    __shared__ double qs[64];
+    const int tid = threadIdx.x;
+    const int overflowed = flags[0];
+    const int E = flags[1];
+    if (tid < 64) qs[tid] = qptr ? qptr[tid] : qa.q[tid];
+    __syncthreads();
+    if (tid < 4) flags[tid] = 0;  // leave the counters zeroed for the next launch (no memset node needed)
+    if (overflowed) {
+        if (tid == 0) { res->count = 0; res->overflow = 1; res->candidates = 0; }
+        return;
+    }
+    select_fast_body(ix, qs, k, cand, E, res);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: batched queries on the matrix cores.  C[N x Q] = E[N x 64] * Q^T is never materialised: a
+// workgroup of 8 waves walks 32-claim tiles of E (staged once in LDS, double-buffered); wave w owns
+// queries 32w..32w+31 and keeps their 64 dims as MFMA B fragments in 32 VGPRs for the whole launch.
+// Per tile a wave issues 32 v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain), so the fp32
+// error bound of the single-query scan holds and the same margin / exact re-rank apply.  The D
+// fragment puts one QUERY on each lane (col = lane & 31) and 16 claims in its registers, so the
+// running threshold of a query is a per-lane register and the since/tag mask is one 32-bit word per
+// tile.  Candidates go to per-query LDS buffers (64 entries); a buffer above 32 entries is sorted in
+// registers by its wave (bitonic across lanes) and cut at k-th - margin.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BQ_THREADS = 512, BQ_WAVES = 8, BQ_MAXQ = 256, BQ_CAP = 64, BQ_TRIG = 32, BQ_TS = 65;
+constexpr int BQ_PERQ = 8192;  // candidate slots per query in HBM (256 workgroups x 32)
+constexpr size_t BQ_LDS = (size_t)BQ_MAXQ * BQ_CAP * 8 + 2 * 32 * BQ_TS * 4 + BQ_MAXQ * 4 * 2;
+
+// sort 64 values (one per lane) descending across the wave
+__device__ __forceinline__ uint64_t wave_sort_desc_reg(uint64_t v, int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            const uint64_t other = __shfl_xor(v, j2);
+            const bool desc_blk = (lane & k2) == 0;
+            const bool lower = (lane & j2) == 0;
+            const uint64_t mx = v > other ? v : other, mn = v > other ? other : v;
+            v = (lower == desc_blk) ? mx : mn;
+        }
+    }
+    return v;
+}
+
+template <bool SINCE, bool TAGS>
+__global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index ix, const double* __restrict__ qmat,
+                                                                   int nq, int k, int64_t since_ms, uint64_t tag_mask,
+                                                                   uint64_t* __restrict__ cand3,
+                                                                   int32_t* __restrict__ qtotal,
+                                                                   int32_t* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* qbuf = reinterpret_cast<uint64_t*>(smem);                                  // [256][64]
+    float* tile = reinterpret_cast<float*>(smem + (size_t)BQ_MAXQ * BQ_CAP * 8);           // [2][32][65]
+    int* qcnt = reinterpret_cast<int*>(smem + (size_t)BQ_MAXQ * BQ_CAP * 8 + 2 * 32 * BQ_TS * 4);
+    uint32_t* qthr = reinterpret_cast<uint32_t*>(qcnt + BQ_MAXQ);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int myq = wave * 32 + j;
+    const bool qactive = myq < nq;
+    const bool wave_active = wave * 32 < nq;
+    const int64_t n = ix.n;
+    const int64_t n_tiles = (n + 31) >> 5;
+    const f32x4* __restrict__ E = reinterpret_cast<const f32x4*>(ix.emb32);
+
+    if (tid < BQ_MAXQ) { qcnt[tid] = 0; qthr[tid] = 0; }
+    float b[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) b[s] = qactive ? (float)qmat[(size_t)myq * 64 + 2 * s + h] : 0.f;
+    uint32_t thr = 0;
+
+    // staging role: thread -> (row, 16-byte chunk) of the 32 x 64 fp32 tile
+    const int srow = tid >> 4, sc4 = tid & 15;
+    auto load_tile = [&](int64_t t) -> f32x4 {
+        const int64_t r = t * 32 + srow;
+        return (t < n_tiles && r < n) ? __builtin_nontemporal_load(&E[r * 16 + sc4]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto store_tile = [&](int buf, f32x4 v) {
+        float* d = tile + (size_t)buf * 32 * BQ_TS + srow * BQ_TS + sc4 * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    };
+    auto compact_query = [&](int q) {
+        const int cnt = qcnt[q];
+        uint64_t v = lane < cnt ? qbuf[(size_t)q * BQ_CAP + lane] : 0ull;
+        v = wave_sort_desc_reg(v, lane);
+        uint32_t t2 = qthr[q];
+        int newcnt = cnt;
+        if (cnt >= k) {
+            const uint64_t kth = __shfl(v, k - 1);
+            const uint32_t nt = lbh_ord32(lbh_unord32((uint32_t)(kth >> 32)) - LBH_MARGIN);
+            if (nt > t2) t2 = nt;
+            newcnt = __popcll(__ballot(lane < cnt && (uint32_t)(v >> 32) >= t2));
+        }
+        if (lane < newcnt) qbuf[(size_t)q * BQ_CAP + lane] = v;
+        if (lane == 0) {
+            qcnt[q] = newcnt;
+            qthr[q] = t2;
+            if (newcnt > BQ_TRIG) atomicOr(&flags[0], 1);  // too many near-ties for this path
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    int64_t t = blockIdx.x;
+    store_tile(0, load_tile(t));
+    __syncthreads();
+    for (int it = 0; t < n_tiles; t += gridDim.x, ++it) {
+        const int buf = it & 1;
+        const f32x4 nx = load_tile(t + gridDim.x);
+        // since / tag mask of the tile's 32 claims as one word
+        bool rv = false;
+        if (lane < 32) {
+            const int64_t r = t * 32 + lane;
+            rv = r < n;
+            if (SINCE) rv = rv && ix.created[rv ? r : 0] >= since_ms;
+            if (TAGS) rv = rv && (ix.tags[r < n ? r : 0] & tag_mask) != 0;
+        }
+        const uint32_t rowmask = (uint32_t)__ballot(rv);
+        if (wave_active) {
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float* tp = tile + (size_t)buf * 32 * BQ_TS + j * BQ_TS + h;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tp[2 * s], b[s], acc, 0, 0, 0);
+            if (qactive) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rowbit = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const uint32_t o = lbh_ord32(acc[r]);
+                    if (((rowmask >> rowbit) & 1u) && o >= thr) {
+                        const int pos = atomicAdd(&qcnt[myq], 1);
+                        if (pos < BQ_CAP) qbuf[(size_t)myq * BQ_CAP + pos] = ((uint64_t)o << 32) | (uint32_t)(t * 32 + rowbit);
+                        else atomicOr(&flags[0], 1);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint64_t need = __ballot(lane < 32 && qactive && qcnt[myq] > BQ_TRIG);
+            if (need) {
+                while (need) {
+                    const int qi = __ffsll((long long)need) - 1;
+                    need &= need - 1;
+                    compact_query(wave * 32 + qi);
+                }
+                if (qactive) thr = qthr[myq];
+            }
+        }
+        store_tile(buf ^ 1, nx);
+        __syncthreads();
+    }
+    // flush: final cut per query, then append to the query's flat candidate list in HBM
+    if (wave_active) {
+        for (int qi = 0; qi < 32 && wave * 32 + qi < nq; ++qi) {
+            const int q = wave * 32 + qi;
+            if (qcnt[q] == 0) continue;
+            compact_query(q);
+            const int cnt = qcnt[q] < BQ_CAP ? qcnt[q] : BQ_CAP;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&qtotal[q], cnt);
+            base = __shfl(base, 0);
+            if (base + cnt > BQ_PERQ) {
+                if (lane == 0) atomicOr(&flags[0], 1);
+            } else if (lane < cnt) {
+                cand3[(size_t)q * BQ_PERQ + base + lane] = qbuf[(size_t)q * BQ_CAP + lane];
+            }
+        }
+    }
+}
+
+// K4 for a batch: one block per query.
+__global__ __launch_bounds__(SEL_THREADS) void select_batched_kernel(lbh_dev_index ix, const double* __restrict__ qmat,
+                                                                      int k, const uint64_t* __restrict__ cand3,
+                                                                      const int32_t* __restrict__ qtotal,
+                                                                      const int32_t* __restrict__ flags,
+                                                                      lbh_result* __restrict__ res_arr) {
+    __shared__ double qs[64];
+    const int tid = threadIdx.x, q = blockIdx.x;
+    lbh_result* res = res_arr + q;
+    if (tid < 64) qs[tid] = qmat[(size_t)q * 64 + tid];
+    __syncthreads();
+    if (flags[0]) {
+        if (tid == 0) { res->count = 0; res->overflow = 1; res->candidates = 0; }
+        return;
+    }
+    int E = qtotal[q];
+    if (E > BQ_PERQ) E = BQ_PERQ;
+    select_fast_body(ix, qs, k, cand3 + (size_t)q * BQ_PERQ, E, res);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -630,5 +813,39 @@ hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace&
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     select_exact_kernel<<<1, SEL_THREADS, 0, s>>>(ix, k, ws.xcand_ord, ws.xcand_row, ws.flags, ws.result_dev);
+    return hipGetLastError();
+}
+
+hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspace& ws, int nq, int k, int has_since,
+                                     int64_t since_ms, uint64_t tag_mask, int n_cu, hipStream_t s, hipEvent_t ev0,
+                                     hipEvent_t ev1) {
+    static bool attr_set = false;
+    hipError_t e;
+    if (!attr_set) {
+        const void* fns[] = {(const void*)scan_batched_kernel<true, true>, (const void*)scan_batched_kernel<true, false>,
+                             (const void*)scan_batched_kernel<false, true>, (const void*)scan_batched_kernel<false, false>};
+        for (const void* f : fns) {
+            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BQ_LDS);
+            if (e != hipSuccess) return e;
+        }
+        attr_set = true;
+    }
+    e = hipMemsetAsync(ws.flags, 0, 16, s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws.bq_total, 0, BQ_MAXQ * 4, s);
+    if (e != hipSuccess) return e;
+    const int64_t tiles = (ix.n + 31) / 32;
+    const dim3 g((unsigned)(tiles < n_cu ? tiles : n_cu)), b(BQ_THREADS);
+    if (ev0) (void)hipEventRecord(ev0, s);
+#define LBH_BSCAN_ARGS ix, ws.bq_qmat, nq, k, since_ms, tag_mask, ws.bq_cand, ws.bq_total, ws.flags
+    if (has_since && tag_mask) scan_batched_kernel<true, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+    else if (has_since) scan_batched_kernel<true, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+    else if (tag_mask) scan_batched_kernel<false, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+    else scan_batched_kernel<false, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+#undef LBH_BSCAN_ARGS
+    if (ev1) (void)hipEventRecord(ev1, s);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    select_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(ix, ws.bq_qmat, k, ws.bq_cand, ws.bq_total, ws.flags, ws.bq_result_dev);
     return hipGetLastError();
 }

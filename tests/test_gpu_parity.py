@@ -249,3 +249,56 @@ def test_tags_extension_matches_oracle(hip):
             assert g.compile(q, top_k=16, tags=tags) == og.compile(q, top_k=16, tags=tags), (q, tags)
         assert g.compile(q, top_k=16, tags=["t00"], since_ms=int(ch.created_ms[2000])) == \
             og.compile(q, top_k=16, tags=["t00"], since_ms=int(ch.created_ms[2000]))
+
+
+def test_batched_queries_mfma_path_vs_oracle(hip):
+    """K3: many queries in one pass on the matrix cores; every query must equal the oracle bit-for-bit."""
+    from lbm_amd import synth
+    ch = _arrays_case(150_000, 123)
+    ix = hip.Index()
+    ids = ix.add_texts(ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)
+    for i in np.nonzero(ch.retracted)[0].tolist():
+        ix.retract(i)
+    emb = orc.embed_batch_packed(ch.blob, ch.offsets)
+    packed = orc.pack_texts(ch.hashes())
+    retr = ch.retracted.astype(np.uint8)
+    texts = synth.make_queries(37, seed=21) + [ch.text(777), ch.text(778) + " " + ch.text(779), ""]
+    qv = hip.embed_batch(texts)
+    p50 = int(ch.created_ms[ch.n // 2])
+    st = hip.Stats()
+    for k, since, tmask in ((8, None, 0), (16, p50, 0), (1, None, 0b110), (8, p50, 1 << 7 | 1)):
+        gi, gs, cnt = ix.search(qv, k, hip.SINCE_NONE if since is None else since, tmask, st)
+        assert st.path == 2 and st.scan_launches >= 1
+        for j in range(len(texts)):
+            want_idx, want_sc = orc.compile_arrays(emb, ch.created_ms, retr, None, qv[j], k, since, ch.tagmask, tmask,
+                                                   packed_keys=packed)
+            n = int(cnt[j])
+            assert gi[j, :n].tolist() == want_idx.tolist(), (k, since, tmask, j)
+            assert gs[j, :n].tobytes() == want_sc.tobytes(), (k, since, tmask, j)
+        assert st.fallbacks >= 1  # the empty query ties every claim at 0.0 -> served by the exact path
+    # 300 queries: two launches of the 256-query kernel
+    many = synth.make_queries(300, seed=5)
+    qm = hip.embed_batch(many)
+    gi, gs, cnt = ix.search(qm, 8, hip.SINCE_NONE, 0, st)
+    assert st.path == 2 and st.scan_launches == 2 and st.fallbacks == 0
+    for j in (0, 1, 128, 255, 256, 257, 299):
+        want_idx, want_sc = orc.compile_arrays(emb, ch.created_ms, retr, None, qm[j], 8, None, packed_keys=packed)
+        assert gi[j, : int(cnt[j])].tolist() == want_idx.tolist() and gs[j, : int(cnt[j])].tobytes() == want_sc.tobytes()
+    ix.close()
+
+
+def test_compile_many_equals_compile(hip):
+    from lbm_amd.context_graph import ContextGraph
+    from lbm_amd import synth
+    ch = synth.make_chunk(0, 5000, seed=8, dup_frac=0.05)
+    g = ContextGraph()
+    texts, hashes = ch.texts(), ch.hashes()
+    for i in range(ch.n):
+        g.add_claim(hashes[i], texts[i], ch.tags(i), created_ms=int(ch.created_ms[i]))
+    qs = synth.make_queries(9, seed=1) + [texts[3], "", "zzz unknown"]
+    since = int(ch.created_ms[2500])
+    for kw in ({"top_k": 8}, {"top_k": 16, "since_ms": since}, {"top_k": 5, "tags": ["t01", "t02"]}, {"top_k": 0},
+               {"top_k": 40}):
+        many = g.compile_many(qs, **kw)
+        assert many == [g.compile(q, **kw) for q in qs], kw
+    assert g.compile_many([], top_k=3) == []
