@@ -23,7 +23,7 @@ SINCE_NONE = -(2 ** 63)
 INT64_MAX = 2 ** 63 - 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblbhip.so")
+LIB_PATH = os.environ.get("LBM_HIP_LIB") or os.path.join(_HERE, "liblbhip.so")  # LBM_HIP_LIB: A/B builds
 
 EXPORTS = [
     "lbh_init", "lbh_shutdown", "lbh_last_error", "lbh_version", "lbh_device_name", "lbh_set_option",

@@ -277,6 +277,7 @@ int ensure_batched_ws(lbh_index* ix) {
     HIP_TRY(hipMalloc((void**)&w.bq_qmat, (size_t)LBH_BQ_MAXQ * 512));
     HIP_TRY(hipMalloc((void**)&w.bq_cand, (size_t)LBH_BQ_MAXQ * LBH_BQ_PERQ * 8));
     HIP_TRY(hipMalloc((void**)&w.bq_total, (size_t)LBH_BQ_MAXQ * 4));
+    HIP_TRY(hipMalloc((void**)&w.bq_seed, (size_t)LBH_BQ_MAXQ * 4));
     HIP_TRY(hipHostMalloc((void**)&w.bq_result_host, sizeof(lbh_result) * LBH_BQ_MAXQ, hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer((void**)&w.bq_result_dev, w.bq_result_host, 0));
     return LBH_OK;
@@ -435,7 +436,7 @@ int lbh_index_destroy(lbh_index* ix) {
     hipStreamSynchronize(ix->ctx->stream);
     lbh_workspace& w = ix->ws;
     void* dev[] = {ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, w.q64, w.cand, w.xcand_ord, w.xcand_row,
-                   w.flags, w.bq_qmat, w.bq_cand, w.bq_total};
+                   w.flags, w.bq_qmat, w.bq_cand, w.bq_total, w.bq_seed};
     for (void* p : dev)
         if (p) hipFree(p);
     if (w.result_host) hipHostFree(w.result_host);

@@ -83,6 +83,7 @@ struct lbh_workspace {
     double* bq_qmat;          // 256 x 64 fp64 query matrix
     uint64_t* bq_cand;        // 256 x LBH_BQ_PERQ flat candidate lists, one per query
     int32_t* bq_total;        // 256 counters
+    uint32_t* bq_seed;        // 256 per-query seed thresholds (ord32) from the sample pass
     lbh_result* bq_result_host;  // 256 results, pinned + device-mapped
     lbh_result* bq_result_dev;
     lbh_result* result_host;  // pinned, device-mapped host memory: the final kernel writes it directly

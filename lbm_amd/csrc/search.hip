@@ -17,6 +17,8 @@
 //
 // This file is compiled with -ffp-contract=off: fp64 arithmetic must round like CPython floats.
 // FMAs in the fp32 scan are written explicitly (fmaf).
+#include <cstdlib>
+
 #include "lbh_internal.h"
 
 namespace {
@@ -448,9 +450,16 @@ __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index 
 // registers by its wave (bitonic across lanes) and cut at k-th - margin.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int BQ_THREADS = 512, BQ_WAVES = 8, BQ_MAXQ = 256, BQ_CAP = 64, BQ_TRIG = 32, BQ_TS = 65;
+#ifndef LBH_BQ_ABLATE
+#define LBH_BQ_ABLATE 0  // 1 / 2: timing-only builds for tools (no MFMA / no epilogue)
+#endif
+constexpr int BQ_THREADS = 512, BQ_WAVES = 8, BQ_MAXQ = 256, BQ_CAP = 56, BQ_TRIG = 24;
+// LDS image of a 64-claim super-tile (double-buffered): row stride 68 floats, each row stored as [even dims | odd dims]
+// so that a lane's 32 A values are contiguous (8 x ds_read_b128, conflict-free at this stride)
+constexpr int BQ_TS = 68, BQ_TILE_F = 64 * BQ_TS, BQ_NBUF = 2;
+constexpr int BQ_OVER = 0x40000000;  // bit of a query's counter: its candidate set could not be bounded here
 constexpr int BQ_PERQ = 8192;  // candidate slots per query in HBM (256 workgroups x 32)
-constexpr size_t BQ_LDS = (size_t)BQ_MAXQ * BQ_CAP * 8 + 2 * 32 * BQ_TS * 4 + BQ_MAXQ * 4 * 2;
+constexpr size_t BQ_LDS = (size_t)BQ_MAXQ * BQ_CAP * 8 + BQ_NBUF * BQ_TILE_F * 4 + BQ_MAXQ * 4 * 2;  // 151,552 B
 
 // sort 64 values (one per lane) descending across the wave
 __device__ __forceinline__ uint64_t wave_sort_desc_reg(uint64_t v, int lane) {
@@ -468,16 +477,100 @@ __device__ __forceinline__ uint64_t wave_sort_desc_reg(uint64_t v, int lane) {
     return v;
 }
 
-template <bool SINCE, bool TAGS>
+struct bq_ctx {          // per-wave view of the K3 candidate state (LDS) for the out-of-line slow path
+    uint64_t* qbuf;
+    int* qcnt;
+    uint32_t* qthr;
+    int32_t* qtotal;
+    int k, lane, wave, myq, h;
+    bool qactive;
+};
+
+// one query's buffer (<= 56 entries, one per lane): find the k-th largest by rank counting (entries are
+// unique: the row sits in the low word), raise the threshold, keep what is still within the margin.
+// No sort: the survivors are re-packed in lane order, which is all the later stages need.
+__device__ __forceinline__ void bq_compact_impl(const bq_ctx& c, int q) {
+    const int lane = c.lane;
+    const int cnt = c.qcnt[q] < BQ_CAP ? c.qcnt[q] : BQ_CAP;  // the counter may have run past a full buffer
+    const uint64_t* buf = c.qbuf + (size_t)q * BQ_CAP;
+    const uint64_t v = lane < cnt ? buf[lane] : 0ull;
+    uint32_t t2 = c.qthr[q];
+    int newcnt = cnt;
+    if (cnt >= c.k) {
+        int rank = 0;  // number of entries strictly greater than mine
+        for (int i = 0; i < cnt; ++i) rank += buf[i] > v;  // wave-uniform address: an LDS broadcast read
+        const uint64_t sel = __ballot(lane < cnt && rank == c.k - 1);
+        const int src = __ffsll((long long)sel) - 1;
+        const uint32_t kth = (uint32_t)(__shfl(v, src) >> 32);
+        const uint32_t nt = lbh_ord32(lbh_unord32(kth) - LBH_MARGIN);
+        if (nt > t2) t2 = nt;
+        const bool keep = lane < cnt && (uint32_t)(v >> 32) >= t2;
+        const uint64_t km = __ballot(keep);
+        newcnt = __popcll(km);
+        const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+        __builtin_amdgcn_wave_barrier();  // every lane holds its entry in a register before the re-pack
+        if (keep) c.qbuf[(size_t)q * BQ_CAP + __popcll(km & lt)] = v;
+    }
+    if (lane == 0) {
+        c.qcnt[q] = newcnt;
+        c.qthr[q] = t2;
+        if (newcnt > BQ_TRIG) atomicOr(&c.qtotal[q], BQ_OVER);  // too many near-ties for this path: that query only
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __noinline__ void bq_compact(const bq_ctx& c, int q) { bq_compact_impl(c, q); }
+
+// slow path of the K3 epilogue: exact ord compare, mask, append, compaction.  Returns the lane's
+// (possibly raised) threshold.  Two flavours: the main pass (thresholds seeded, a candidate is rare)
+// calls it OUT OF LINE so that it costs the MFMA loop no registers -- a call spills the caller's live
+// registers around it, which is fine when rare; the sample pass (cold thresholds: every tile has
+// candidates) inlines it, because there the spill traffic of a call per tile dominated everything.
+template <bool INL>
+__device__ __forceinline__ uint32_t bq_harvest_impl(const bq_ctx& c, const f32x16& acc, int64_t row0, uint32_t rowmask,
+                                                    uint32_t thr) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rowbit = (r & 3) + 8 * (r >> 2) + 4 * c.h;
+        const uint32_t o = lbh_ord32(acc[r]);
+        const bool pass = c.qactive && ((rowmask >> rowbit) & 1u) && o >= thr;
+        if (__any(pass)) {  // wave-uniform skip: in steady state almost every register has no candidate
+            if (pass) {
+                const int pos = atomicAdd(&c.qcnt[c.myq], 1);
+                if (pos < BQ_CAP) c.qbuf[(size_t)c.myq * BQ_CAP + pos] = ((uint64_t)o << 32) | (uint32_t)(row0 + rowbit);
+                else atomicOr(&c.qtotal[c.myq], BQ_OVER);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint64_t need = __ballot(c.lane < 32 && c.qactive && c.qcnt[c.myq] > BQ_TRIG);
+    if (need) {
+        while (need) {
+            const int qi = __ffsll((long long)need) - 1;
+            need &= need - 1;
+            if (INL) bq_compact_impl(c, c.wave * 32 + qi);
+            else bq_compact(c, c.wave * 32 + qi);
+        }
+        if (c.qactive) thr = c.qthr[c.myq];
+    }
+    return thr;
+}
+__device__ __noinline__ uint32_t bq_harvest(const bq_ctx& c, f32x16 acc, int64_t row0, uint32_t rowmask, uint32_t thr) {
+    return bq_harvest_impl<false>(c, acc, row0, rowmask, thr);
+}
+
+template <bool SINCE, bool TAGS, bool WARM>
 __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index ix, const double* __restrict__ qmat,
                                                                    int nq, int k, int64_t since_ms, uint64_t tag_mask,
+                                                                   int64_t row_begin, int64_t row_end,
+                                                                   const uint32_t* __restrict__ seed,
                                                                    uint64_t* __restrict__ cand3,
                                                                    int32_t* __restrict__ qtotal,
                                                                    int32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* qbuf = reinterpret_cast<uint64_t*>(smem);                                  // [256][64]
-    float* tile = reinterpret_cast<float*>(smem + (size_t)BQ_MAXQ * BQ_CAP * 8);           // [2][32][65]
-    int* qcnt = reinterpret_cast<int*>(smem + (size_t)BQ_MAXQ * BQ_CAP * 8 + 2 * 32 * BQ_TS * 4);
+    float* tile = reinterpret_cast<float*>(smem + (size_t)BQ_MAXQ * BQ_CAP * 8);           // [2][64][68]
+    int* qcnt = reinterpret_cast<int*>(smem + (size_t)BQ_MAXQ * BQ_CAP * 8 + BQ_NBUF * BQ_TILE_F * 4);
     uint32_t* qthr = reinterpret_cast<uint32_t*>(qcnt + BQ_MAXQ);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -485,92 +578,115 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
     const int myq = wave * 32 + j;
     const bool qactive = myq < nq;
     const bool wave_active = wave * 32 < nq;
-    const int64_t n = ix.n;
-    const int64_t n_tiles = (n + 31) >> 5;
+    const int64_t n = row_end < ix.n ? row_end : ix.n;  // this launch scans rows [row_begin, n)
     const f32x4* __restrict__ E = reinterpret_cast<const f32x4*>(ix.emb32);
 
-    if (tid < BQ_MAXQ) { qcnt[tid] = 0; qthr[tid] = 0; }
+    // seed: per-query lower bounds on the final threshold (k-th best of a sample pass - margin)
+    if (tid < BQ_MAXQ) { qcnt[tid] = 0; qthr[tid] = (seed && tid < nq) ? seed[tid] : 0u; }
     float b[32];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) b[s] = qactive ? (float)qmat[(size_t)myq * 64 + 2 * s + h] : 0.f;
-    uint32_t thr = 0;
+    for (int s = 0; s < 32; ++s) {
+        // unconditional load from a clamped row, then select: a load under a lane-dependent branch would
+        // be waited for on the spot (32 serial round trips)
+        const float v = (float)qmat[(size_t)(qactive ? myq : 0) * 64 + 2 * s + h];
+        b[s] = qactive ? v : 0.f;
+    }
+    uint32_t thr = (seed && qactive) ? seed[myq] : 0u;
 
-    // staging role: thread -> (row, 16-byte chunk) of the 32 x 64 fp32 tile
+    // staging role: a super-tile is 64 claims (two MFMA tiles); thread -> (row, 16-byte chunk) x 2
     const int srow = tid >> 4, sc4 = tid & 15;
-    auto load_tile = [&](int64_t t) -> f32x4 {
-        const int64_t r = t * 32 + srow;
-        return (t < n_tiles && r < n) ? __builtin_nontemporal_load(&E[r * 16 + sc4]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    auto load_half = [&](int64_t st, int half) -> f32x4 {
+        // always load (row clamped into the matrix): a guarded load is waited for inside its branch, which
+        // would expose the HBM latency every super-tile; rows >= n are dropped by row_mask() instead
+        int64_t r = row_begin + st * 64 + half * 32 + srow;
+        r = r < n ? r : n - 1;
+        return __builtin_nontemporal_load(&E[r * 16 + sc4]);
     };
-    auto store_tile = [&](int buf, f32x4 v) {
-        float* d = tile + (size_t)buf * 32 * BQ_TS + srow * BQ_TS + sc4 * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    auto store_half = [&](int buf, int half, f32x4 v) {
+        float* d = tile + (size_t)buf * BQ_TILE_F + (half * 32 + srow) * BQ_TS + 2 * sc4;
+        *reinterpret_cast<f32x2*>(d) = f32x2{v.x, v.z};        // even dims 4c, 4c+2  -> slots 2c, 2c+1
+        *reinterpret_cast<f32x2*>(d + 32) = f32x2{v.y, v.w};   // odd dims            -> 32 + 2c, 32 + 2c+1
     };
-    auto compact_query = [&](int q) {
-        const int cnt = qcnt[q];
-        uint64_t v = lane < cnt ? qbuf[(size_t)q * BQ_CAP + lane] : 0ull;
-        v = wave_sort_desc_reg(v, lane);
-        uint32_t t2 = qthr[q];
-        int newcnt = cnt;
-        if (cnt >= k) {
-            const uint64_t kth = __shfl(v, k - 1);
-            const uint32_t nt = lbh_ord32(lbh_unord32((uint32_t)(kth >> 32)) - LBH_MARGIN);
-            if (nt > t2) t2 = nt;
-            newcnt = __popcll(__ballot(lane < cnt && (uint32_t)(v >> 32) >= t2));
-        }
-        if (lane < newcnt) qbuf[(size_t)q * BQ_CAP + lane] = v;
-        if (lane == 0) {
-            qcnt[q] = newcnt;
-            qthr[q] = t2;
-            if (newcnt > BQ_TRIG) atomicOr(&flags[0], 1);  // too many near-ties for this path
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
+    bq_ctx bc;
+    bc.qbuf = qbuf; bc.qcnt = qcnt; bc.qthr = qthr; bc.qtotal = qtotal;
+    bc.k = k; bc.lane = lane; bc.wave = wave; bc.myq = myq; bc.h = h; bc.qactive = qactive;
+    auto compact_query = [&](int q) { bq_compact(bc, q); };
 
-    int64_t t = blockIdx.x;
-    store_tile(0, load_tile(t));
-    __syncthreads();
-    for (int it = 0; t < n_tiles; t += gridDim.x, ++it) {
-        const int buf = it & 1;
-        const f32x4 nx = load_tile(t + gridDim.x);
-        // since / tag mask of the tile's 32 claims as one word
+    // rows of one 32-claim tile that pass the since / tag filters, as one word (lanes 0..31 vote)
+    auto row_mask = [&](int64_t row0) -> uint32_t {
         bool rv = false;
         if (lane < 32) {
-            const int64_t r = t * 32 + lane;
+            const int64_t r = row0 + lane;
             rv = r < n;
             if (SINCE) rv = rv && ix.created[rv ? r : 0] >= since_ms;
             if (TAGS) rv = rv && (ix.tags[r < n ? r : 0] & tag_mask) != 0;
         }
-        const uint32_t rowmask = (uint32_t)__ballot(rv);
-        if (wave_active) {
-            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const float* tp = tile + (size_t)buf * 32 * BQ_TS + j * BQ_TS + h;
+        return (uint32_t)__ballot(rv);
+    };
+    // float image of thr: a cheap superset test in the common case (idle lanes never hit)
+    float thr_f = qactive ? (thr ? lbh_unord32(thr) : -__builtin_inff()) : __builtin_inff();
+    auto harvest = [&](const f32x16& acc, int64_t row0, uint32_t rowmask) {
+        if (WARM) thr = bq_harvest_impl<true>(bc, acc, row0, rowmask, thr);
+        else thr = bq_harvest(bc, acc, row0, rowmask, thr);
+        if (qactive) thr_f = thr ? lbh_unord32(thr) : -__builtin_inff();
+    };
+    auto any_hit = [&](const f32x16& acc) -> bool {
+        bool hit = false;
 #pragma unroll
-            for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tp[2 * s], b[s], acc, 0, 0, 0);
-            if (qactive) {
+        for (int r = 0; r < 16; ++r) hit |= acc[r] >= thr_f;
+        return __any(hit);
+    };
+
+    // A fragments of the current super-tile live in registers; the LDS image is double-buffered so one
+    // barrier per super-tile is enough (the image being filled was last read two barriers ago).
+    const int64_t n_super = n > row_begin ? (n - row_begin + 63) >> 6 : 0;
+    const int64_t G = gridDim.x;
+    int64_t st = blockIdx.x;
+    float a0[32], a1[32];
+    auto read_frags = [&](int buf) {
+        const f32x4* p0 = reinterpret_cast<const f32x4*>(tile + (size_t)buf * BQ_TILE_F + j * BQ_TS + h * 32);
+        const f32x4* p1 = reinterpret_cast<const f32x4*>(tile + (size_t)buf * BQ_TILE_F + (32 + j) * BQ_TS + h * 32);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rowbit = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const uint32_t o = lbh_ord32(acc[r]);
-                    if (((rowmask >> rowbit) & 1u) && o >= thr) {
-                        const int pos = atomicAdd(&qcnt[myq], 1);
-                        if (pos < BQ_CAP) qbuf[(size_t)myq * BQ_CAP + pos] = ((uint64_t)o << 32) | (uint32_t)(t * 32 + rowbit);
-                        else atomicOr(&flags[0], 1);
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            uint64_t need = __ballot(lane < 32 && qactive && qcnt[myq] > BQ_TRIG);
-            if (need) {
-                while (need) {
-                    const int qi = __ffsll((long long)need) - 1;
-                    need &= need - 1;
-                    compact_query(wave * 32 + qi);
-                }
-                if (qactive) thr = qthr[myq];
-            }
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 u = p0[i], w = p1[i];
+            a0[4 * i] = u.x; a0[4 * i + 1] = u.y; a0[4 * i + 2] = u.z; a0[4 * i + 3] = u.w;
+            a1[4 * i] = w.x; a1[4 * i + 1] = w.y; a1[4 * i + 2] = w.z; a1[4 * i + 3] = w.w;
         }
-        store_tile(buf ^ 1, nx);
+    };
+    store_half(0, 0, load_half(st, 0));
+    store_half(0, 1, load_half(st, 1));
+    f32x4 nx0 = load_half(st + G, 0), nx1 = load_half(st + G, 1);
+    __syncthreads();
+    if (wave_active) read_frags(0);
+    for (int it = 0; st < n_super; st += G, ++it) {
+        store_half((it + 1) & 1, 0, nx0);   // super-tile it+1 (prefetched during the previous iteration)
+        store_half((it + 1) & 1, 1, nx1);
+        nx0 = load_half(st + 2 * G, 0);
+        nx1 = load_half(st + 2 * G, 1);
+        if (wave_active) {
+            const int64_t row0 = row_begin + st * 64;
+            const uint32_t m0 = row_mask(row0), m1 = row_mask(row0 + 32);
+            f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 acc1 = acc0;
+#if LBH_BQ_ABLATE == 1  // timing-only build: no matrix work
+#pragma unroll
+            for (int s = 0; s < 32; ++s) { acc0[s & 15] += a0[s] * b[s]; acc1[s & 15] += a1[s] * b[s]; }
+#else
+#pragma unroll
+            for (int s = 0; s < 32; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b[s], acc0, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 32; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b[s], acc1, 0, 0, 0);
+#endif
+#if LBH_BQ_ABLATE == 2  // timing-only build: no epilogue
+            asm volatile("" ::"v"(acc0), "v"(acc1));
+#else
+            if (any_hit(acc0)) harvest(acc0, row0, m0);
+            if (any_hit(acc1)) harvest(acc1, row0 + 32, m1);
+#endif
+        }
         __syncthreads();
+        if (wave_active) read_frags((it + 1) & 1);
     }
     // flush: final cut per query, then append to the query's flat candidate list in HBM
     if (wave_active) {
@@ -580,15 +696,41 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
             compact_query(q);
             const int cnt = qcnt[q] < BQ_CAP ? qcnt[q] : BQ_CAP;
             int base = 0;
-            if (lane == 0) base = atomicAdd(&qtotal[q], cnt);
+            if (lane == 0) base = atomicAdd(&qtotal[q], cnt) & (BQ_OVER - 1);
             base = __shfl(base, 0);
             if (base + cnt > BQ_PERQ) {
-                if (lane == 0) atomicOr(&flags[0], 1);
+                if (lane == 0) atomicOr(&qtotal[q], BQ_OVER);
             } else if (lane < cnt) {
                 cand3[(size_t)q * BQ_PERQ + base + lane] = qbuf[(size_t)q * BQ_CAP + lane];
             }
         }
     }
+}
+
+// Per-query seed threshold from the sample pass: (k-th best fp32 score of the sample) - margin.  The
+// sample is a subset of the corpus, so this never exceeds the final cut (global k-th - margin).
+__global__ __launch_bounds__(SEL_THREADS) void seed_batched_kernel(int k, const uint64_t* __restrict__ cand3,
+                                                                    int32_t* __restrict__ qtotal,
+                                                                    uint32_t* __restrict__ seed) {
+    __shared__ int hist[256];
+    __shared__ int64_t sh_krem;
+    __shared__ int sh_bin;
+    const int q = blockIdx.x;
+    const int raw = qtotal[q];
+    int E = raw & (BQ_OVER - 1);
+    if (E > BQ_PERQ) E = BQ_PERQ;
+    const uint64_t* cand = cand3 + (size_t)q * BQ_PERQ;
+    uint32_t thr = 0;
+    if (E >= k) {
+        auto val = [&](int e, uint64_t* v) {
+            *v = cand[e] >> 32;
+            return true;
+        };
+        const uint32_t kth = (uint32_t)block_radix_select(E, 4, k, val, hist, &sh_krem, &sh_bin);
+        thr = lbh_ord32(lbh_unord32(kth) - LBH_MARGIN);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { seed[q] = thr; qtotal[q] = raw & BQ_OVER; }
 }
 
 // K4 for a batch: one block per query.
@@ -602,11 +744,12 @@ __global__ __launch_bounds__(SEL_THREADS) void select_batched_kernel(lbh_dev_ind
     lbh_result* res = res_arr + q;
     if (tid < 64) qs[tid] = qmat[(size_t)q * 64 + tid];
     __syncthreads();
-    if (flags[0]) {
+    const int raw = qtotal[q];
+    if (flags[0] || (raw & BQ_OVER)) {
         if (tid == 0) { res->count = 0; res->overflow = 1; res->candidates = 0; }
         return;
     }
-    int E = qtotal[q];
+    int E = raw;
     if (E > BQ_PERQ) E = BQ_PERQ;
     select_fast_body(ix, qs, k, cand3 + (size_t)q * BQ_PERQ, E, res);
 }
@@ -822,8 +965,10 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspac
     static bool attr_set = false;
     hipError_t e;
     if (!attr_set) {
-        const void* fns[] = {(const void*)scan_batched_kernel<true, true>, (const void*)scan_batched_kernel<true, false>,
-                             (const void*)scan_batched_kernel<false, true>, (const void*)scan_batched_kernel<false, false>};
+        const void* fns[] = {(const void*)scan_batched_kernel<true, true, false>, (const void*)scan_batched_kernel<true, false, false>,
+                             (const void*)scan_batched_kernel<false, true, false>, (const void*)scan_batched_kernel<false, false, false>,
+                             (const void*)scan_batched_kernel<true, true, true>, (const void*)scan_batched_kernel<true, false, true>,
+                             (const void*)scan_batched_kernel<false, true, true>, (const void*)scan_batched_kernel<false, false, true>};
         for (const void* f : fns) {
             e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BQ_LDS);
             if (e != hipSuccess) return e;
@@ -834,15 +979,54 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspac
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws.bq_total, 0, BQ_MAXQ * 4, s);
     if (e != hipSuccess) return e;
-    const int64_t tiles = (ix.n + 31) / 32;
-    const dim3 g((unsigned)(tiles < n_cu ? tiles : n_cu)), b(BQ_THREADS);
-    if (ev0) (void)hipEventRecord(ev0, s);
-#define LBH_BSCAN_ARGS ix, ws.bq_qmat, nq, k, since_ms, tag_mask, ws.bq_cand, ws.bq_total, ws.flags
-    if (has_since && tag_mask) scan_batched_kernel<true, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
-    else if (has_since) scan_batched_kernel<true, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
-    else if (tag_mask) scan_batched_kernel<false, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
-    else scan_batched_kernel<false, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+    const dim3 b(BQ_THREADS);
+    auto launch = [&](int64_t r0, int64_t r1, const uint32_t* seed) {
+        const int64_t tiles = (r1 - r0 + 63) / 64;
+        const dim3 g((unsigned)(tiles < n_cu ? tiles : n_cu));
+#define LBH_BSCAN_ARGS ix, ws.bq_qmat, nq, k, since_ms, tag_mask, r0, r1, seed, ws.bq_cand, ws.bq_total, ws.flags
+        if (true) {  // the flavour with the slow path inlined (no spills at 200 VGPRs; a call per candidate tile cost more)
+            if (has_since && tag_mask) scan_batched_kernel<true, true, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+            else if (has_since) scan_batched_kernel<true, false, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+            else if (tag_mask) scan_batched_kernel<false, true, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+            else scan_batched_kernel<false, false, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+        } else {
+            if (has_since && tag_mask) scan_batched_kernel<true, true, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+            else if (has_since) scan_batched_kernel<true, false, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+            else if (tag_mask) scan_batched_kernel<false, true, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+            else scan_batched_kernel<false, false, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+        }
 #undef LBH_BSCAN_ARGS
+    };
+    if (ev0) (void)hipEventRecord(ev0, s);
+    // Sample passes seed every query's threshold before the full pass: with cold thresholds nearly every
+    // tile holds candidates and the (VALU + LDS) harvest path, not the matrix pipe, sets the pace.  Each
+    // pass scans the first n >> shift rows starting from the previous pass's seeds (a subset's k-th best
+    // never exceeds the corpus's, so seeds are always valid lower bounds).  Default: n/512, then n/32
+    // (measured at 10 M x 256: 0.21 + 0.16 ms of sample passes, 2.78 ms full pass; see profiles/).
+    static int shifts[4] = {9, 5, 0, 0};
+    static int n_shifts = -1;
+    if (n_shifts < 0) {
+        n_shifts = 2;
+        if (const char* ev = getenv("LBH_BQ_SAMPLE_SHIFTS")) {  // e.g. "9,5" (default), "6", "" = none
+            n_shifts = 0;
+            for (const char* p = ev; *p && n_shifts < 4;) {
+                char* end;
+                const long v = strtol(p, &end, 10);
+                if (end == p) break;
+                if (v > 0 && v < 32) shifts[n_shifts++] = (int)v;
+                p = (*end == ',') ? end + 1 : end;
+            }
+        }
+    }
+    const uint32_t* seed = nullptr;
+    for (int i = 0; i < n_shifts; ++i) {
+        const int64_t ns = ((ix.n >> shifts[i]) / 64) * 64;
+        if (ns < 16384) continue;
+        launch(0, ns, seed);
+        seed_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(k, ws.bq_cand, ws.bq_total, ws.bq_seed);
+        seed = ws.bq_seed;
+    }
+    launch(0, ix.n, seed);
     if (ev1) (void)hipEventRecord(ev1, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
