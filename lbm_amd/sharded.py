@@ -59,16 +59,18 @@ class ShardedSearcher:
     """
 
     def __init__(self, local_search: Callable, rank: int, world: int, *, device=None, group=None,
-                 gid_of_local: Optional[Callable[[np.ndarray], np.ndarray]] = None) -> None:
+                 gid_of_local: Optional[Callable[[np.ndarray], np.ndarray]] = None,
+                 always_gather: bool = False) -> None:
         self.local_search, self.rank, self.world = local_search, rank, world
         self.device, self.group = device, group
+        self.always_gather = always_gather  # run the collective even for world == 1 (tests)
         self.gid_of_local = gid_of_local or (lambda ids: ids.astype(np.uint64) * np.uint64(world) + np.uint64(rank))
 
     def search(self, q: np.ndarray, k: int, since_ms: int, tag_mask: int = 0):
         k = max(0, int(k))
         ids, scores, keys = self.local_search(q, k, since_ms, tag_mask)
         local = pack_local(scores, self.gid_of_local(np.asarray(ids)), keys, k)
-        if self.world == 1:
+        if self.world == 1 and not self.always_gather:
             return merge_gathered(local[None], k)
         import torch
         import torch.distributed as dist

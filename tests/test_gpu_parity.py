@@ -302,3 +302,30 @@ def test_compile_many_equals_compile(hip):
         many = g.compile_many(qs, **kw)
         assert many == [g.compile(q, **kw) for q in qs], kw
     assert g.compile_many([], top_k=3) == []
+
+
+def test_sharded_searcher_over_rccl_single_rank(hip):
+    """The N > 1 code path of bench.py on the one GPU we have: RCCL process group of size 1, device tensors
+    through all_gather_into_tensor, merge -- must equal the plain search."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from lbm_amd import synth
+    from lbm_amd.sharded import ShardedSearcher
+    ch = _arrays_case(50_000, 9)
+    ix = hip.Index()
+    ix.add_texts(ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        s = ShardedSearcher(ix.search_shard, 0, 1, device=torch.device("cuda", 0), always_gather=True)
+        qv = hip.embed_batch(synth.make_queries(4, seed=3))
+        for q in qv:
+            for k in (8, 64):
+                gi, gs, _ = s.search(q, k, hip.SINCE_NONE, 0)
+                wi, ws, _ = ix.search_shard(q, k, hip.SINCE_NONE, 0)
+                assert gi.tolist() == wi.tolist() and gs.tobytes() == ws.tobytes()
+    finally:
+        dist.destroy_process_group()
+        ix.close()
