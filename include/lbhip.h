@@ -44,7 +44,8 @@ typedef struct lbh_index lbh_index;
 /* Per-search statistics (all optional; pass NULL to skip).  Times are HIP-event
  * times on the library's own stream. */
 typedef struct lbh_stats {
-    int32_t want_timing;      /* in: non-zero = record HIP events around the kernels below */
+    int32_t want_timing;      /* in: 1 = HIP events around the scan kernel(s) (scan_ms); 2 = also around the whole call
+                                 (total_ms).  Each event record costs a few microseconds of queue time. */
     int32_t path;             /* out: 0 = fp32 scan + exact re-rank, 1 = exact fp64 scan (fallback / paging), 2 = batched MFMA */
     int64_t rows_scanned;     /* out: live rows the scoring kernel read */
     int64_t bytes_per_row;    /* out: algorithmic bytes per row for that kernel (256/264/272 or 512+..) */
@@ -52,7 +53,7 @@ typedef struct lbh_stats {
     int32_t scan_launches;    /* out: number of scoring-kernel launches this call made */
     int32_t fallbacks;        /* out: times the fp32 path overflowed into the exact path */
     float scan_ms;            /* out: total HIP-event time of the scoring kernel launches */
-    float total_ms;           /* out: HIP-event time of everything enqueued by the call */
+    float total_ms;           /* out: HIP-event time of everything enqueued by the call (want_timing >= 2, else 0) */
 } lbh_stats;
 
 /* ---- context -------------------------------------------------------------- */

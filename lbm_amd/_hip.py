@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 import threading
 from typing import Optional, Sequence, Tuple
 
@@ -59,6 +60,30 @@ _i64 = ctypes.c_int64
 _u64 = ctypes.c_uint64
 
 
+def _preload_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7) and ask for it as plain `libamdhip64.so`, which the dynamic linker does not match
+    against an already loaded /opt/rocm copy: if liblbhip.so pulled in the system runtime first, torch
+    would bring up a second runtime that finds no GPU ("ProcessGroupNCCL ... no GPUs found").  Loading
+    the bundled copy first makes liblbhip.so's `libamdhip64.so.7` dependency bind to it, and torch later
+    re-uses the same file.  Without torch (or with LBM_HIP_SYSTEM_RUNTIME=1) the RUNPATH copy is used."""
+    if os.environ.get("LBM_HIP_SYSTEM_RUNTIME") == "1" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the RUNPATH runtime; torch then has to be imported before lbm_amd
+
+
 def load_library() -> ctypes.CDLL:
     """dlopen liblbhip.so and declare every prototype of include/lbhip.h.  Needs no GPU."""
     global _lib
@@ -69,6 +94,7 @@ def load_library() -> ctypes.CDLL:
             raise HipBackendError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C lbm_amd/csrc`). lbm_amd has no CPU fallback.")
+        _preload_torch_hip_runtime()
         try:
             L = ctypes.CDLL(LIB_PATH)
         except OSError as e:  # missing ROCm runtime etc.

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <string>
@@ -45,6 +46,7 @@ struct lbh_ctx {
     std::string arch;
     int scan_blocks_per_cu = 2;  // tuning knobs (env LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT), see DESIGN.md
     int scan_nt = 1;
+    int spin_us = 5000;  // poll the completion ticket this long before blocking in hipStreamSynchronize (0 = always block)
     std::mutex mu;  // serialises use of the scratch below
     // small scratch for embed / cosine calls
     uint8_t* d_text = nullptr;
@@ -69,6 +71,7 @@ struct lbh_index {
     lbh_workspace ws{};
     lbh_qarg qarg{};              // current query when it came from the host (kernel argument)
     const double* qptr = nullptr;  // current query when it was embedded on the GPU (ws.q64), else NULL
+    int32_t seq = 0;          // completion ticket of the last single-query launch
     void* staging = nullptr;  // pinned host staging
     int64_t staging_cap = 0;
 };
@@ -78,21 +81,21 @@ namespace {
 int ensure_ctx_scratch(lbh_ctx* c, int64_t text_bytes, int64_t n_off, int64_t n_vec) {
     HIP_TRY(hipSetDevice(c->device));
     if (text_bytes > c->d_text_cap) {
-        if (c->d_text) hipFree(c->d_text);
+        if (c->d_text) (void)hipFree(c->d_text);
         c->d_text = nullptr;
         int64_t cap = std::max<int64_t>(text_bytes, 1 << 16);
         HIP_TRY(hipMalloc((void**)&c->d_text, (size_t)cap));
         c->d_text_cap = cap;
     }
     if (n_off > c->d_off_cap) {
-        if (c->d_off) hipFree(c->d_off);
+        if (c->d_off) (void)hipFree(c->d_off);
         c->d_off = nullptr;
         int64_t cap = std::max<int64_t>(n_off, 1024);
         HIP_TRY(hipMalloc((void**)&c->d_off, (size_t)cap * 8));
         c->d_off_cap = cap;
     }
     if (n_vec > c->d_vec_cap) {
-        if (c->d_vec) hipFree(c->d_vec);
+        if (c->d_vec) (void)hipFree(c->d_vec);
         c->d_vec = nullptr;
         int64_t cap = std::max<int64_t>(n_vec, 1024);
         HIP_TRY(hipMalloc((void**)&c->d_vec, (size_t)cap * 8));
@@ -107,7 +110,7 @@ int grow_array(T*& p, int64_t old_n, int64_t new_cap, int64_t per_row, hipStream
     HIP_TRY(hipMalloc((void**)&q, (size_t)new_cap * per_row * sizeof(T)));
     if (p && old_n > 0) HIP_TRY(hipMemcpyAsync(q, p, (size_t)old_n * per_row * sizeof(T), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (p) hipFree(p);
+    if (p) (void)hipFree(p);
     p = q;
     return LBH_OK;
 }
@@ -129,7 +132,7 @@ int index_reserve_locked(lbh_index* ix, int64_t want) {
 
 int ensure_staging(lbh_index* ix, int64_t bytes) {
     if (bytes <= ix->staging_cap) return LBH_OK;
-    if (ix->staging) hipHostFree(ix->staging);
+    if (ix->staging) (void)hipHostFree(ix->staging);
     ix->staging = nullptr;
     int64_t cap = std::max<int64_t>(bytes, 1 << 20);
     HIP_TRY(hipHostMalloc(&ix->staging, (size_t)cap, hipHostMallocDefault));
@@ -183,14 +186,30 @@ int run_page(lbh_index* ix, int page, int64_t since_ms, uint64_t tag_mask, bool 
     bool fast = allow_fast && !cur.active;
     for (;;) {
         hipEvent_t e0 = timing ? c->ev[0] : nullptr, e1 = timing ? c->ev[1] : nullptr;
+        const int32_t seq = ix->seq = (ix->seq == INT32_MAX) ? 1 : ix->seq + 1;
         if (fast)
-            HIP_TRY(lbh_launch_search_fast(dv, ix->ws, ix->qptr, ix->qarg, page, has_since, since_ms, tag_mask, grid, c->scan_nt, s, e0, e1));
+            HIP_TRY(lbh_launch_search_fast(dv, ix->ws, ix->qptr, ix->qarg, page, has_since, since_ms, tag_mask, grid, c->scan_nt, seq, s, e0, e1));
         else {
             const int xgrid = std::min(grid, 512);
-            HIP_TRY(lbh_launch_search_exact(dv, ix->ws, ix->qptr, ix->qarg, page, has_since, since_ms, tag_mask, cur, xgrid, s, e0, e1));
+            HIP_TRY(lbh_launch_search_exact(dv, ix->ws, ix->qptr, ix->qarg, page, has_since, since_ms, tag_mask, cur, xgrid, seq, s, e0, e1));
         }
-        HIP_TRY(hipStreamSynchronize(s));
         const lbh_result* r = ix->ws.result_host;
+        // Latency path: the final kernel writes the result block into mapped host memory and publishes the
+        // ticket last, so polling it skips the runtime's completion hand-off.  Bounded: past spin_us (a hung
+        // or faulted kernel, or a very long scan) fall back to the stream, which also reports device errors.
+        bool done = false;
+        if (c->spin_us > 0) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int it = 0;; ++it) {
+                if (__atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) == seq) { done = true; break; }
+                __builtin_ia32_pause();
+                if ((it & 255) == 255 &&
+                    std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > c->spin_us)
+                    break;
+            }
+        }
+        if (!done) HIP_TRY(hipStreamSynchronize(s));
+        if (timing) HIP_TRY(hipEventSynchronize(c->ev[1]));
         acc->scan_launches += 1;
         acc->rows_scanned = ix->n;
         if (timing) {
@@ -227,7 +246,8 @@ int search_loaded(lbh_index* ix, int64_t k, int64_t since_ms, uint64_t tag_mask,
     const bool timing = stats && stats->want_timing;
     SearchAcc acc;
     int64_t got = 0;
-    if (timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    const bool timing_total = timing && stats->want_timing >= 2;  // two more event records per call
+    if (timing_total) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     if (k > 0 && ix->n > 0) {
         lbh_cursor cur;
         memset(&cur, 0, sizeof cur);
@@ -254,10 +274,10 @@ int search_loaded(lbh_index* ix, int64_t k, int64_t since_ms, uint64_t tag_mask,
     *out_count = got;
     if (stats) {
         float total = 0.f;
-        if (timing) {
+        if (timing_total) {
             HIP_TRY(hipEventRecord(c->ev[3], c->stream));
             HIP_TRY(hipEventSynchronize(c->ev[3]));
-            hipEventElapsedTime(&total, c->ev[2], c->ev[3]);
+            (void)hipEventElapsedTime(&total, c->ev[2], c->ev[3]);
         }
         stats->path = acc.path;
         stats->rows_scanned = acc.rows_scanned;
@@ -318,6 +338,7 @@ int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx) {
     c->arch = prop.gcnArchName;
     if (const char* e1 = getenv("LBH_SCAN_BLOCKS_PER_CU")) c->scan_blocks_per_cu = std::max(1, std::min(8, atoi(e1)));
     if (const char* e2 = getenv("LBH_SCAN_NT")) c->scan_nt = atoi(e2) != 0;
+    if (const char* e3 = getenv("LBH_SPIN_US")) c->spin_us = std::max(0, std::min(1000000, atoi(e3)));
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& ev : c->ev) HIP_TRY(hipEventCreate(&ev));
@@ -327,14 +348,14 @@ int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx) {
 
 int lbh_shutdown(lbh_ctx* c) {
     if (!c) return LBH_OK;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    if (c->d_text) hipFree(c->d_text);
-    if (c->d_off) hipFree(c->d_off);
-    if (c->d_vec) hipFree(c->d_vec);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_text) (void)hipFree(c->d_text);
+    if (c->d_off) (void)hipFree(c->d_off);
+    if (c->d_vec) (void)hipFree(c->d_vec);
     for (auto& ev : c->ev)
-        if (ev) hipEventDestroy(ev);
-    if (c->stream) hipStreamDestroy(c->stream);
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return LBH_OK;
 }
@@ -350,6 +371,7 @@ int lbh_set_option(lbh_ctx* c, const char* name, int64_t value) {
     std::lock_guard<std::mutex> lk(c->mu);
     if (!strcmp(name, "scan_blocks_per_cu")) c->scan_blocks_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "scan_nt")) c->scan_nt = value != 0;
+    else if (!strcmp(name, "spin_us")) c->spin_us = (int)std::max<int64_t>(0, std::min<int64_t>(1000000, value));
     else return fail(LBH_E_INVALID, "unknown option %s", name);
     return LBH_OK;
 }
@@ -422,7 +444,7 @@ int lbh_index_create(lbh_ctx* c, lbh_index** out_idx) {
     HIP_TRY(hipMalloc((void**)&w.xcand_ord, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 8));
     HIP_TRY(hipMalloc((void**)&w.xcand_row, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 4));
     HIP_TRY(hipMalloc((void**)&w.flags, 256));
-    HIP_TRY(hipHostMalloc((void**)&w.result_host, sizeof(lbh_result), hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void**)&w.result_host, sizeof(lbh_result), hipHostMallocMapped | hipHostMallocCoherent));
     HIP_TRY(hipHostGetDevicePointer((void**)&w.result_dev, w.result_host, 0));
     memset(w.result_host, 0, sizeof(lbh_result));
     HIP_TRY(hipMemset(w.flags, 0, 256));
@@ -432,16 +454,16 @@ int lbh_index_create(lbh_ctx* c, lbh_index** out_idx) {
 
 int lbh_index_destroy(lbh_index* ix) {
     if (!ix) return LBH_OK;
-    hipSetDevice(ix->ctx->device);
-    hipStreamSynchronize(ix->ctx->stream);
+    (void)hipSetDevice(ix->ctx->device);
+    (void)hipStreamSynchronize(ix->ctx->stream);
     lbh_workspace& w = ix->ws;
     void* dev[] = {ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, w.q64, w.cand, w.xcand_ord, w.xcand_row,
                    w.flags, w.bq_qmat, w.bq_cand, w.bq_total, w.bq_seed};
     for (void* p : dev)
-        if (p) hipFree(p);
-    if (w.result_host) hipHostFree(w.result_host);
-    if (w.bq_result_host) hipHostFree(w.bq_result_host);
-    if (ix->staging) hipHostFree(ix->staging);
+        if (p) (void)hipFree(p);
+    if (w.result_host) (void)hipHostFree(w.result_host);
+    if (w.bq_result_host) (void)hipHostFree(w.bq_result_host);
+    if (ix->staging) (void)hipHostFree(ix->staging);
     delete ix;
     return LBH_OK;
 }

@@ -67,7 +67,7 @@ struct lbh_result {
     int32_t count;
     int32_t overflow;         // fp32 path could not bound its candidate set -> caller re-runs exactly
     int32_t candidates;       // rows that were re-scored in fp64
-    int32_t pad;
+    int32_t seq;              // completion ticket: written last, after a system-scope fence (see publish_result)
     uint32_t rows[LBH_MAX_PAGE];
     double scores[LBH_MAX_PAGE];
     uint64_t keys[LBH_MAX_PAGE][4];   // hash keys of the results (shard merge, paging cursor)
@@ -102,11 +102,11 @@ hipError_t lbh_launch_move_row(float* emb32, double* emb64, int64_t* created, ui
 int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu);
 hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
                                   const lbh_qarg& qa, int k, int has_since,
-                                  int64_t since_ms, uint64_t tag_mask, int grid, int nt, hipStream_t s,
-                                  hipEvent_t ev0, hipEvent_t ev1);
+                                  int64_t since_ms, uint64_t tag_mask, int grid, int nt, int seq,
+                                  hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
                                    const lbh_qarg& qa, int k, int has_since,
-                                   int64_t since_ms, uint64_t tag_mask, const lbh_cursor& cur, int grid,
+                                   int64_t since_ms, uint64_t tag_mask, const lbh_cursor& cur, int grid, int seq,
                                    hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspace& ws, int nq, int k, int has_since,
                                      int64_t since_ms, uint64_t tag_mask, int n_cu, hipStream_t s, hipEvent_t ev0,

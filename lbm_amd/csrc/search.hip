@@ -418,12 +418,21 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
     rerank_and_emit(xo, xr, M, k, ix, qs, res, false);
 }
 
+// Completion ticket: the result block lives in device-mapped pinned host memory, so once every writer
+// has fenced to system scope thread 0 publishes the caller's sequence number and the host may read the
+// block as soon as it sees that number (no stream synchronisation on the latency path).
+__device__ __forceinline__ void publish_result(lbh_result* res, int seq) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&res->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // K4 (fast path, one query): one block.
 __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index ix, const double* __restrict__ qptr,
                                                                    lbh_qarg qa, int k,
                                                                    const uint64_t* __restrict__ cand,
                                                                    int32_t* __restrict__ flags,
-                                                                   lbh_result* __restrict__ res) {
+                                                                   lbh_result* __restrict__ res, int seq) {
     __shared__ double qs[64];
     const int tid = threadIdx.x;
     const int overflowed = flags[0];
@@ -433,9 +442,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index 
     if (tid < 4) flags[tid] = 0;  // leave the counters zeroed for the next launch (no memset node needed)
     if (overflowed) {
         if (tid == 0) { res->count = 0; res->overflow = 1; res->candidates = 0; }
-        return;
+    } else {
+        select_fast_body(ix, qs, k, cand, E, res);
     }
-    select_fast_body(ix, qs, k, cand, E, res);
+    publish_result(res, seq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -453,7 +463,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef LBH_BQ_ABLATE
 #define LBH_BQ_ABLATE 0  // 1 / 2: timing-only builds for tools (no MFMA / no epilogue)
 #endif
-constexpr int BQ_THREADS = 512, BQ_WAVES = 8, BQ_MAXQ = 256, BQ_CAP = 56, BQ_TRIG = 24;
+constexpr int BQ_THREADS = 512, BQ_MAXQ = 256, BQ_CAP = 56, BQ_TRIG = 24;
 // LDS image of a 64-claim super-tile (double-buffered): row stride 68 floats, each row stored as [even dims | odd dims]
 // so that a lane's 32 A values are contiguous (8 x ds_read_b128, conflict-free at this stride)
 constexpr int BQ_TS = 68, BQ_TILE_F = 64 * BQ_TS, BQ_NBUF = 2;
@@ -842,7 +852,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_exact_kernel(lbh_dev_index
                                                                     const uint64_t* __restrict__ xc_ord,
                                                                     const uint32_t* __restrict__ xc_row,
                                                                     int32_t* __restrict__ flags,
-                                                                    lbh_result* __restrict__ res) {
+                                                                    lbh_result* __restrict__ res, int seq) {
     __shared__ uint64_t sbuf[2 * LBH_MCAP];
     __shared__ int hist[256];
     __shared__ int64_t sh_krem;
@@ -896,9 +906,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_exact_kernel(lbh_dev_index
     const int M = sh_cnt;
     if (M > LBH_MCAP) {
         if (tid == 0) { res->count = 0; res->overflow = 2; res->candidates = M; }
-        return;
+    } else {
+        rerank_and_emit(xo, xr, M, k, ix, nullptr, res, true);
     }
-    rerank_and_emit(xo, xr, M, k, ix, nullptr, res, true);
+    publish_result(res, seq);
 }
 
 }  // namespace
@@ -914,8 +925,8 @@ int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu) {
 
 hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
                                   const lbh_qarg& qa, int k, int has_since,
-                                  int64_t since_ms, uint64_t tag_mask, int grid, int nt, hipStream_t s,
-                                  hipEvent_t ev0, hipEvent_t ev1) {
+                                  int64_t since_ms, uint64_t tag_mask, int grid, int nt, int seq,
+                                  hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     hipError_t e;
     if (ev0) (void)hipEventRecord(ev0, s);
     const dim3 g(grid), b(LBH_SCAN_THREADS);
@@ -935,13 +946,13 @@ hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const lbh_workspace& 
     if (ev1) (void)hipEventRecord(ev1, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, qptr, qa, k, ws.cand, ws.flags, ws.result_dev);
+    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, qptr, qa, k, ws.cand, ws.flags, ws.result_dev, seq);
     return hipGetLastError();
 }
 
 hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
                                    const lbh_qarg& qa, int k, int has_since,
-                                   int64_t since_ms, uint64_t tag_mask, const lbh_cursor& cur, int grid,
+                                   int64_t since_ms, uint64_t tag_mask, const lbh_cursor& cur, int grid, int seq,
                                    hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     hipError_t e;
     if (ev0) (void)hipEventRecord(ev0, s);
@@ -955,7 +966,7 @@ hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace&
     if (ev1) (void)hipEventRecord(ev1, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    select_exact_kernel<<<1, SEL_THREADS, 0, s>>>(ix, k, ws.xcand_ord, ws.xcand_row, ws.flags, ws.result_dev);
+    select_exact_kernel<<<1, SEL_THREADS, 0, s>>>(ix, k, ws.xcand_ord, ws.xcand_row, ws.flags, ws.result_dev, seq);
     return hipGetLastError();
 }
 

@@ -16,7 +16,7 @@ for s in range(0, n, chunk):
     v = rng.standard_normal((m, 64)); v /= np.linalg.norm(v, axis=1, keepdims=True)
     ix.add_vectors(v, np.arange(s, s + m, dtype=np.int64), None, rng.integers(0, 256, size=(m, 32), dtype=np.uint8))
 qs = rng.standard_normal((16, 64)); qs /= np.linalg.norm(qs, axis=1, keepdims=True)
-st = _hip.Stats(); st.want_timing = 1
+st = _hip.Stats(); st.want_timing = 2
 configs = [(b, nt) for b in (2, 3, 4, 5, 6, 8) for nt in (0, 1)]
 res = {c: [] for c in configs}; tot = {c: [] for c in configs}
 for rnd in range(6):
