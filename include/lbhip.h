@@ -141,6 +141,23 @@ int lbh_index_search_shard(lbh_index* idx, const double* q_f64, int64_t k, int64
                            uint64_t* out_ids, double* out_scores, uint8_t* out_keys, int64_t* out_count,
                            lbh_stats* stats);
 
+/* ---- next row N3: recency query ------------------------------ */
+
+/* replaces the loop + sort + slice of BatteryNode.get_recent_claims (lb/node.py:750-762): live claims
+ * with created_ms >= since_ms (LBH_SINCE_NONE = no bound), newest first; claims that share a
+ * created_ms come in ascending `order` (the reference's list.sort is stable, so ties keep the claims
+ * dict's insertion order).  limit = max(0, limit) of the reference's claims[:limit]; any value (paged
+ * internally beyond LBH_MAX_PAGE).  out_ids / out_created (may be NULL) receive out_count entries;
+ * out_matched (may be NULL) receives the number of live claims that pass the time bound, whatever the
+ * limit.  stats->path is 3, bytes_per_row 8. */
+int lbh_index_recent(lbh_index* idx, int64_t since_ms, int64_t limit, uint64_t* out_ids, int64_t* out_created,
+                     int64_t* out_count, int64_t* out_matched, lbh_stats* stats);
+
+/* Insertion-order keys used to break created_ms ties in lbh_index_recent.  A claim's order defaults
+ * to its claim id (the order of lbh_index_add calls); a host whose `claims` dict order differs
+ * (re-added hashes keep their old dict position, lb/context_graph.py:72) overrides it here. */
+int lbh_index_set_order(lbh_index* idx, int64_t n, const uint64_t* ids, const uint64_t* order);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,7 @@ EXPORTS = [
     "lbh_index_create", "lbh_index_destroy", "lbh_index_reserve", "lbh_index_add", "lbh_index_retract",
     "lbh_index_update_meta", "lbh_index_set_keys", "lbh_index_size", "lbh_index_get_embedding",
     "lbh_index_search", "lbh_index_search_text", "lbh_index_search_shard",
+    "lbh_index_recent", "lbh_index_set_order",
 ]
 
 
@@ -122,6 +123,9 @@ def load_library() -> ctypes.CDLL:
         L.lbh_index_search.argtypes = [_vp, _vp, _i64, _i64, _i64, _u64, _vp, _vp, _vp, ctypes.POINTER(Stats)]
         L.lbh_index_search_text.argtypes = [_vp, _vp, _i64, _i64, _i64, _u64, _vp, _vp, ctypes.POINTER(_i64), _vp,
                                             ctypes.POINTER(Stats)]
+        L.lbh_index_recent.argtypes = [_vp, _i64, _i64, _vp, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64),
+                                       ctypes.POINTER(Stats)]
+        L.lbh_index_set_order.argtypes = [_vp, _i64, _vp, _vp]
         L.lbh_index_search_shard.argtypes = [_vp, _vp, _i64, _i64, _u64, _vp, _vp, _vp, ctypes.POINTER(_i64),
                                              ctypes.POINTER(Stats)]
         for name in EXPORTS:
@@ -280,6 +284,21 @@ class Index:
         ids = np.ascontiguousarray(ids, dtype=np.uint64)
         keys = np.ascontiguousarray(keys, dtype=np.uint8).reshape(ids.shape[0], KEY_BYTES)
         _check(self._L.lbh_index_set_keys(self._h, ids.shape[0], _ptr(ids), _ptr(keys)))
+
+    def set_order(self, ids: np.ndarray, order: np.ndarray) -> None:
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        order = np.ascontiguousarray(order, dtype=np.uint64).reshape(ids.shape[0])
+        _check(self._L.lbh_index_set_order(self._h, ids.shape[0], _ptr(ids), _ptr(order)))
+
+    def recent(self, since_ms: int = SINCE_NONE, limit: int = 100, stats: Optional[Stats] = None):
+        """Newest-first claim ids with created_ms >= since_ms.  Returns (ids, created_ms, matched)."""
+        limit = max(0, min(int(limit), self.size()))
+        ids = np.zeros(max(limit, 1), dtype=np.uint64)
+        created = np.zeros(max(limit, 1), dtype=np.int64)
+        cnt, matched = _i64(0), _i64(0)
+        _check(self._L.lbh_index_recent(self._h, int(since_ms), limit, _ptr(ids), _ptr(created), ctypes.byref(cnt),
+                                        ctypes.byref(matched), ctypes.byref(stats) if stats is not None else None))
+        return ids[:cnt.value], created[:cnt.value], int(matched.value)
 
     def get_embedding(self, cid: int) -> np.ndarray:
         out = np.empty(DIM, dtype=np.float64)

@@ -27,6 +27,7 @@ How the mirror works
 """
 from __future__ import annotations
 
+import operator
 import re
 import time
 from dataclasses import dataclass
@@ -37,6 +38,7 @@ import numpy as np
 from . import _hip
 
 _HEX64 = re.compile(r"[0-9a-f]{64}\Z")
+_HEXRUN = re.compile(r"[0-9a-f]*\Z")
 MAX_TAG_BITS = 64
 
 
@@ -94,29 +96,38 @@ class _ClaimDict(dict):
             v.__dict__["_lbm_owner"] = (self._g, k)
         self._g._touch(k)
 
+    def _forget(self, k) -> None:
+        self._g._seq_of.pop(k, None)  # a re-inserted key goes to the END of the dict order
+        self._g._touch(k)
+
     def __setitem__(self, k, v) -> None:
+        if k not in self:  # assigning to an existing key keeps its position in the dict order
+            g = self._g
+            g._seq_of[k] = g._next_seq
+            g._next_seq += 1
+            g._order_pending[k] = None  # a popped and re-inserted claim may still own its device row
         super().__setitem__(k, v)
         self._adopt(k, v)
 
     def __delitem__(self, k) -> None:
         super().__delitem__(k)
-        self._g._touch(k)
+        self._forget(k)
 
     def pop(self, k, *default):
         had = k in self
         r = super().pop(k, *default)
         if had:
-            self._g._touch(k)
+            self._forget(k)
         return r
 
     def popitem(self):
         k, v = super().popitem()
-        self._g._touch(k)
+        self._forget(k)
         return k, v
 
     def clear(self) -> None:
         for k in list(self.keys()):
-            self._g._touch(k)
+            self._forget(k)
         super().clear()
 
     def setdefault(self, k, default=None):
@@ -218,6 +229,9 @@ class ContextGraph:
         self._tag_overflow = False
         self._rank_keys = False
         self._keys_stale = False
+        self._seq_of: Dict[str, int] = {}      # hash -> position stamp in the ``claims`` dict order
+        self._next_seq = 0
+        self._order_pending: Dict[str, None] = {}  # rows whose stamp is not on the device yet (recency query only)
         self._index_obj: Optional[_hip.Index] = None
         self.claims: Dict[str, Claim] = _ClaimDict(self)
         self._embedding_cache = _EmbeddingCacheView(self)
@@ -307,7 +321,7 @@ class ContextGraph:
             hs = [h for h, _, _ in new_vec]
             created = np.array([int(c.created_ms) for _, _, c in new_vec], dtype=np.int64)
             tmask = np.array([self._tagmask(c.tags) for _, _, c in new_vec], dtype=np.uint64)
-            keys = np.frombuffer(b"".join(self._key_bytes(h) for h in hs), dtype=np.uint8)
+            keys = self._keys_of(hs)
             ids = self._index.add_vectors(np.stack([v for _, v, _ in new_vec]), created, tmask, keys)
             self._register(hs, ids, created, tmask)
         if new_text:
@@ -315,17 +329,29 @@ class ContextGraph:
             blob, offsets = _hip.pack_texts([t for _, t, _ in new_text])
             created = np.array([int(c.created_ms) for _, _, c in new_text], dtype=np.int64)
             tmask = np.array([self._tagmask(c.tags) for _, _, c in new_text], dtype=np.uint64)
-            keys = np.frombuffer(b"".join(self._key_bytes(h) for h in hs), dtype=np.uint8)
+            keys = self._keys_of(hs)
             ids = self._index.add_texts(blob, offsets, created, tmask, keys)
             self._register(hs, ids, created, tmask)
         if self._rank_keys and (self._keys_stale or new_vec or new_text):
             self._refresh_rank_keys()
 
     def _register(self, hs: Sequence[str], ids: np.ndarray, created: np.ndarray, tmask: np.ndarray) -> None:
-        for h, cid, cm, tm in zip(hs, ids.tolist(), created.tolist(), tmask.tolist()):
-            self._id_of[h] = cid
-            self._hash_of[cid] = h
-            self._meta[h] = (cm, tm)
+        idl = ids.tolist()
+        self._order_pending.update(zip(hs, [None] * len(idl)))
+        self._id_of.update(zip(hs, idl))
+        self._hash_of.update(zip(idl, hs))
+        self._meta.update(zip(hs, zip(created.tolist(), tmask.tolist())))
+
+    def _keys_of(self, hs: Sequence[str]) -> np.ndarray:
+        """32-byte ordering keys of a batch of hashes (one bulk hex decode when they are all sha256 hex)."""
+        if not self._rank_keys:
+            try:
+                joined = "".join(hs)
+                if len(joined) == 64 * len(hs) and _HEXRUN.match(joined) and all(len(h) == 64 for h in hs):
+                    return np.frombuffer(bytes.fromhex(joined), dtype=np.uint8)
+            except TypeError:
+                pass
+        return np.frombuffer(b"".join(self._key_bytes(h) for h in hs), dtype=np.uint8)
 
     # ------------------------------------------------------------------ reference API
 
@@ -424,6 +450,45 @@ class ContextGraph:
             return [], []
         ids, scores, _ = index.search_text(query, k, since, tag_mask, stats)
         return [self._hash_of[i] for i in ids.tolist()], scores.tolist()
+
+    def recent(self, since_ms, limit: Optional[int] = 100) -> List[str]:
+        """Claim hashes of ``BatteryNode.get_recent_claims`` (lb/node.py:750-762) in the reference's order:
+        live claims with ``created_ms >= since_ms``, newest first, ties in ``claims`` dict order, then
+        ``[:limit]`` with Python's slice semantics (negative = drop from the end, None = all).  One masked
+        top-``limit`` over the device's created_ms column (8 B/claim) instead of a Python loop + sort."""
+        self._sync()
+        if limit is not None:
+            limit = operator.index(limit)  # a slice bound: TypeError for floats, like claims[:limit]
+        index = self._index
+        if isinstance(since_ms, float):
+            if since_ms != since_ms or since_ms == float("inf"):
+                return []  # created_ms >= since_ms holds for no claim
+            since = _hip.SINCE_NONE if since_ms == float("-inf") else int(np.ceil(since_ms))
+        else:
+            since = int(since_ms)
+        if since > _hip.INT64_MAX:
+            return []
+        since = max(since, _hip.SINCE_NONE)
+        if not self._id_of:
+            return []
+        if self._order_pending:
+            hs = [h for h in self._order_pending if h in self._id_of]
+            self._order_pending = {}
+            if hs:
+                index.set_order(np.array([self._id_of[h] for h in hs], dtype=np.uint64),
+                                np.array([self._seq_of[h] for h in hs], dtype=np.uint64))
+        n = len(self._id_of)
+        if limit is None:
+            want = n
+        elif limit < 0:
+            _, _, matched = index.recent(since, 0)
+            want = max(0, matched + limit)
+        else:
+            want = min(limit, n)
+        if want == 0:
+            return []
+        ids, _, _ = index.recent(since, want)
+        return [self._hash_of[i] for i in ids.tolist()]
 
     def compile_many(self, queries: Sequence[str], *, top_k: int = 8, since_ms: Optional[int] = None,
                      tags: Optional[Sequence[str]] = None) -> List[Tuple[str, List[str]]]:

@@ -66,6 +66,7 @@ struct lbh_index {
     int64_t* created = nullptr;
     uint64_t* tags = nullptr;
     uint64_t* keys = nullptr;
+    uint64_t* order = nullptr;    // per-row insertion-order key of the recency query (defaults to the claim id)
     std::vector<uint64_t> id_of_row;
     std::vector<int64_t> row_of_id;
     lbh_workspace ws{};
@@ -126,6 +127,7 @@ int index_reserve_locked(lbh_index* ix, int64_t want) {
     if ((rc = grow_array(ix->created, ix->n, want, 1, s))) return rc;
     if ((rc = grow_array(ix->tags, ix->n, want, 1, s))) return rc;
     if ((rc = grow_array(ix->keys, ix->n, want, 4, s))) return rc;
+    if ((rc = grow_array(ix->order, ix->n, want, 1, s))) return rc;
     ix->cap = want;
     return LBH_OK;
 }
@@ -161,6 +163,24 @@ inline void store_be64(uint8_t* p, uint64_t v) {
     memcpy(p, &v, 8);
 }
 
+// Latency path: the final kernel of a query writes its result block into mapped host memory and
+// publishes the ticket last, so polling it skips the runtime's completion hand-off.  Bounded: past
+// spin_us (a hung or faulted kernel, or a very long scan) fall back to the stream, which also reports
+// device errors.
+hipError_t wait_ticket(lbh_ctx* c, const int32_t* ticket, int32_t seq) {
+    if (c->spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int it = 0;; ++it) {
+            if (__atomic_load_n(ticket, __ATOMIC_ACQUIRE) == seq) return hipSuccess;
+            __builtin_ia32_pause();
+            if ((it & 255) == 255 &&
+                std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > c->spin_us)
+                break;
+        }
+    }
+    return hipStreamSynchronize(c->stream);
+}
+
 struct PageOut {
     int count = 0;
     uint32_t rows[LBH_MAX_PAGE];
@@ -194,21 +214,7 @@ int run_page(lbh_index* ix, int page, int64_t since_ms, uint64_t tag_mask, bool 
             HIP_TRY(lbh_launch_search_exact(dv, ix->ws, ix->qptr, ix->qarg, page, has_since, since_ms, tag_mask, cur, xgrid, seq, s, e0, e1));
         }
         const lbh_result* r = ix->ws.result_host;
-        // Latency path: the final kernel writes the result block into mapped host memory and publishes the
-        // ticket last, so polling it skips the runtime's completion hand-off.  Bounded: past spin_us (a hung
-        // or faulted kernel, or a very long scan) fall back to the stream, which also reports device errors.
-        bool done = false;
-        if (c->spin_us > 0) {
-            const auto t0 = std::chrono::steady_clock::now();
-            for (int it = 0;; ++it) {
-                if (__atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) == seq) { done = true; break; }
-                __builtin_ia32_pause();
-                if ((it & 255) == 255 &&
-                    std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > c->spin_us)
-                    break;
-            }
-        }
-        if (!done) HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(wait_ticket(c, &r->seq, seq));
         if (timing) HIP_TRY(hipEventSynchronize(c->ev[1]));
         acc->scan_launches += 1;
         acc->rows_scanned = ix->n;
@@ -300,6 +306,23 @@ int ensure_batched_ws(lbh_index* ix) {
     HIP_TRY(hipMalloc((void**)&w.bq_seed, (size_t)LBH_BQ_MAXQ * 4));
     HIP_TRY(hipHostMalloc((void**)&w.bq_result_host, sizeof(lbh_result) * LBH_BQ_MAXQ, hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer((void**)&w.bq_result_dev, w.bq_result_host, 0));
+    return LBH_OK;
+}
+
+int ensure_recent_ws(lbh_index* ix) {
+    lbh_workspace& w = ix->ws;
+    if (w.rc_result_host) return LBH_OK;
+    const size_t cap = (size_t)LBH_RC_MAX_BLOCKS * LBH_MAX_PAGE;
+    if (!w.rc_a) HIP_TRY(hipMalloc((void**)&w.rc_a, cap * 8));
+    if (!w.rc_b) HIP_TRY(hipMalloc((void**)&w.rc_b, cap * 8));
+    if (!w.rc_row) HIP_TRY(hipMalloc((void**)&w.rc_row, cap * 4));
+    if (!w.rc_cnt) HIP_TRY(hipMalloc((void**)&w.rc_cnt, 64));
+    HIP_TRY(hipMemset(w.rc_cnt, 0, 64));
+    lbh_recent_result* h = nullptr;
+    HIP_TRY(hipHostMalloc((void**)&h, sizeof(lbh_recent_result), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(h, 0, sizeof *h);
+    HIP_TRY(hipHostGetDevicePointer((void**)&w.rc_result_dev, h, 0));
+    w.rc_result_host = h;
     return LBH_OK;
 }
 
@@ -457,12 +480,13 @@ int lbh_index_destroy(lbh_index* ix) {
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
     lbh_workspace& w = ix->ws;
-    void* dev[] = {ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, w.q64, w.cand, w.xcand_ord, w.xcand_row,
+    void* dev[] = {ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, ix->order, w.rc_a, w.rc_b, w.rc_row, w.rc_cnt, w.q64, w.cand, w.xcand_ord, w.xcand_row,
                    w.flags, w.bq_qmat, w.bq_cand, w.bq_total, w.bq_seed};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     if (w.result_host) (void)hipHostFree(w.result_host);
     if (w.bq_result_host) (void)hipHostFree(w.bq_result_host);
+    if (w.rc_result_host) (void)hipHostFree(w.rc_result_host);
     if (ix->staging) (void)hipHostFree(ix->staging);
     delete ix;
     return LBH_OK;
@@ -503,6 +527,7 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
     HIP_TRY(hipMemcpyAsync(ix->created + r0, h_created, (size_t)n * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(ix->tags + r0, h_tags, (size_t)n * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(ix->keys + r0 * 4, h_keys, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(lbh_launch_iota_u64(ix->order + r0, (uint64_t)ix->row_of_id.size(), n, s));
     if (emb_f64) {
         HIP_TRY(hipMemcpyAsync(ix->emb64 + r0 * 64, emb_f64, (size_t)n * 512, hipMemcpyHostToDevice, s));
         HIP_TRY(lbh_launch_f64_to_f32(ix->emb64 + r0 * 64, ix->emb32 + r0 * 64, n * 64, s));
@@ -548,7 +573,7 @@ int lbh_index_retract(lbh_index* ix, uint64_t id) {
     HIP_TRY(hipSetDevice(ix->ctx->device));
     const int64_t r = ix->row_of_id[(size_t)id], last = ix->n - 1;
     if (r != last) {
-        HIP_TRY(lbh_launch_move_row(ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, r, last, ix->ctx->stream));
+        HIP_TRY(lbh_launch_move_row(ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, ix->order, r, last, ix->ctx->stream));
         const uint64_t moved = ix->id_of_row[(size_t)last];
         ix->id_of_row[(size_t)r] = moved;
         ix->row_of_id[(size_t)moved] = r;
@@ -593,6 +618,96 @@ int lbh_index_set_keys(lbh_index* ix, int64_t n, const uint64_t* ids, const uint
     }
     HIP_TRY(hipMemcpyAsync(ix->keys, host.data(), host.size() * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return LBH_OK;
+}
+
+int lbh_index_set_order(lbh_index* ix, int64_t n, const uint64_t* ids, const uint64_t* order) {
+    if (!ix || n < 0 || (n > 0 && (!ids || !order))) return fail(LBH_E_INVALID, "bad argument");
+    if (n == 0) return LBH_OK;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIP_TRY(hipSetDevice(ix->ctx->device));
+    hipStream_t s = ix->ctx->stream;
+    int rc = ensure_staging(ix, n * 16);
+    if (rc) return rc;
+    int64_t* h_rows = reinterpret_cast<int64_t*>(ix->staging);
+    uint64_t* h_vals = reinterpret_cast<uint64_t*>(h_rows + n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (ids[i] >= ix->row_of_id.size() || ix->row_of_id[(size_t)ids[i]] < 0)
+            return fail(LBH_E_NOTFOUND, "unknown claim id %llu", (unsigned long long)ids[i]);
+        h_rows[i] = ix->row_of_id[(size_t)ids[i]];
+        h_vals[i] = order[i];
+    }
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, (size_t)n * 16));
+    hipError_t e = hipMemcpyAsync(d, ix->staging, (size_t)n * 16, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess)
+        e = lbh_launch_scatter_u64(ix->order, reinterpret_cast<const int64_t*>(d), reinterpret_cast<const uint64_t*>(d) + n, n, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    HIP_TRY(e);
+    return LBH_OK;
+}
+
+int lbh_index_recent(lbh_index* ix, int64_t since_ms, int64_t limit, uint64_t* out_ids, int64_t* out_created,
+                     int64_t* out_count, int64_t* out_matched, lbh_stats* stats) {
+    if (!ix || !out_count) return fail(LBH_E_INVALID, "bad argument");
+    if (limit < 0) limit = 0;
+    if (limit > 0 && !out_ids) return fail(LBH_E_INVALID, "output arrays are NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    lbh_ctx* c = ix->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    *out_count = 0;
+    if (out_matched) *out_matched = 0;
+    if (stats) {
+        const int32_t wt = stats->want_timing;
+        memset(stats, 0, sizeof *stats);
+        stats->want_timing = wt;
+        stats->path = 3;
+    }
+    if (ix->n == 0) return LBH_OK;
+    int rc = ensure_recent_ws(ix);
+    if (rc) return rc;
+    const bool timing = stats && stats->want_timing;
+    const int has_since = since_ms != LBH_SINCE_NONE;
+    lbh_rcursor cur;
+    memset(&cur, 0, sizeof cur);
+    int64_t got = 0, remaining = std::min<int64_t>(limit, ix->n);
+    const lbh_recent_result* r = ix->ws.rc_result_host;
+    bool first = true;
+    int64_t anchor = ix->n;  // where the threshold seed looks: the index tail, then just below the last page's rows
+    while (first || remaining > 0) {  // one pass even for limit 0: it still reports `matched`
+        const int page = (int)std::max<int64_t>(1, std::min<int64_t>(remaining, LBH_MAX_PAGE));
+        const int32_t seq = ix->seq = (ix->seq == INT32_MAX) ? 1 : ix->seq + 1;
+        HIP_TRY(lbh_launch_recent(ix->created, ix->order, ix->n, ix->ws, page, has_since, since_ms, cur, anchor, c->n_cu, seq,
+                                  c->stream, timing ? c->ev[0] : nullptr, timing ? c->ev[1] : nullptr));
+        HIP_TRY(wait_ticket(c, &r->seq, seq));
+        if (timing) {
+            HIP_TRY(hipEventSynchronize(c->ev[1]));
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) stats->scan_ms += ms;
+        }
+        if (stats) {
+            stats->scan_launches += 1;
+            stats->rows_scanned = ix->n;
+            stats->bytes_per_row = 8;
+        }
+        if (first && out_matched) *out_matched = r->matched;
+        first = false;
+        const int take = (int)std::min<int64_t>(r->count, remaining);
+        for (int i = 0; i < take; ++i) {
+            out_ids[got + i] = ix->id_of_row[r->rows[i]];
+            if (out_created) out_created[got + i] = r->created[i];
+        }
+        got += take;
+        remaining -= take;
+        if (r->count < page || take == 0) break;
+        for (int i = 0; i < r->count; ++i) anchor = std::min<int64_t>(anchor, r->rows[i]);
+        cur.active = 1;
+        cur.a = (uint64_t)r->created[r->count - 1] ^ 0x8000000000000000ull;
+        cur.b = ~r->order[r->count - 1];
+    }
+    *out_count = got;
+    if (stats) stats->candidates = got;
     return LBH_OK;
 }
 

@@ -195,13 +195,26 @@ __global__ void f64_to_f32_kernel(const double* __restrict__ in, float* __restri
 
 // swap-delete support: copy row `src` over row `dst` in every per-claim array
 __global__ void move_row_kernel(float* emb32, double* emb64, int64_t* created, uint64_t* tags, uint64_t* keys,
-                                int64_t dst, int64_t src) {
+                                uint64_t* order, int64_t dst, int64_t src) {
     const int l = threadIdx.x;
     emb32[dst * 64 + l] = emb32[src * 64 + l];
     emb64[dst * 64 + l] = emb64[src * 64 + l];
     if (l < 4) keys[dst * 4 + l] = keys[src * 4 + l];
     if (l == 4) created[dst] = created[src];
     if (l == 5) tags[dst] = tags[src];
+    if (l == 6) order[dst] = order[src];
+}
+
+// order[r0 + i] = first + i: rows appended without an explicit order sort by insertion
+__global__ void iota_u64_kernel(uint64_t* dst, uint64_t first, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = first + (uint64_t)i;
+}
+
+// dst[rows[i]] = vals[i]  (rows are distinct: one claim id maps to one row)
+__global__ void scatter_u64_kernel(uint64_t* dst, const int64_t* __restrict__ rows, const uint64_t* __restrict__ vals, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[rows[i]] = vals[i];
 }
 
 }  // namespace
@@ -229,7 +242,19 @@ hipError_t lbh_launch_f64_to_f32(const double* in_dev, float* out_dev, int64_t n
 }
 
 hipError_t lbh_launch_move_row(float* emb32, double* emb64, int64_t* created, uint64_t* tags, uint64_t* keys,
-                               int64_t dst, int64_t src, hipStream_t s) {
-    move_row_kernel<<<1, 64, 0, s>>>(emb32, emb64, created, tags, keys, dst, src);
+                               uint64_t* order, int64_t dst, int64_t src, hipStream_t s) {
+    move_row_kernel<<<1, 64, 0, s>>>(emb32, emb64, created, tags, keys, order, dst, src);
+    return hipGetLastError();
+}
+
+hipError_t lbh_launch_iota_u64(uint64_t* dst, uint64_t first, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    iota_u64_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, s>>>(dst, first, n);
+    return hipGetLastError();
+}
+
+hipError_t lbh_launch_scatter_u64(uint64_t* dst, const int64_t* rows_dev, const uint64_t* vals_dev, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    scatter_u64_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, s>>>(dst, rows_dev, vals_dev, n);
     return hipGetLastError();
 }

@@ -73,6 +73,25 @@ struct lbh_result {
     uint64_t keys[LBH_MAX_PAGE][4];   // hash keys of the results (shard merge, paging cursor)
 };
 
+// cursor for paging the recency query: only rows strictly AFTER (a, b) in (created desc, order asc) pass
+struct lbh_rcursor {
+    int32_t active;
+    uint64_t a;        // created_ms with the sign bit flipped (unsigned order = signed order)
+    uint64_t b;        // ~order (larger = earlier in insertion order)
+};
+
+// result block of the recency query (device-mapped pinned host memory, like lbh_result)
+struct lbh_recent_result {
+    int32_t count;
+    int32_t seq;              // completion ticket, written last
+    int64_t matched;          // live rows with created_ms >= since_ms (whole index, cursor ignored)
+    uint32_t rows[LBH_MAX_PAGE];
+    int64_t created[LBH_MAX_PAGE];
+    uint64_t order[LBH_MAX_PAGE];
+};
+
+#define LBH_RC_MAX_BLOCKS 512                   // recency scan grid cap (entries per block <= LBH_MAX_PAGE)
+
 struct lbh_workspace {
     double* q64;              // 64: query embedded on the GPU (search_text); vector queries travel as kernargs
     uint64_t* cand;           // flat, LBH_MAX_BLOCKS x LBH_LIST_CAP entries (ord32<<32 | row)   fast path
@@ -86,6 +105,13 @@ struct lbh_workspace {
     uint32_t* bq_seed;        // 256 per-query seed thresholds (ord32) from the sample pass
     lbh_result* bq_result_host;  // 256 results, pinned + device-mapped
     lbh_result* bq_result_dev;
+    // recency query (get_recent_claims) workspace, allocated on first use
+    uint64_t* rc_a;           // LBH_RC_MAX_BLOCKS x LBH_MAX_PAGE candidate keys: created (biased)
+    uint64_t* rc_b;           //                                                  ~order
+    uint32_t* rc_row;
+    unsigned long long* rc_cnt;  // [0] entries in rc_*, [1] matched rows, [4..6] threshold seed (set, a, b)
+    lbh_recent_result* rc_result_host;
+    lbh_recent_result* rc_result_dev;
     lbh_result* result_host;  // pinned, device-mapped host memory: the final kernel writes it directly
     lbh_result* result_dev;   // device-side address of result_host
 };
@@ -97,7 +123,9 @@ hipError_t lbh_launch_embed(const uint8_t* utf8_dev, const int64_t* offsets_dev,
 hipError_t lbh_launch_cosine(const double* a_dev, const double* b_dev, int64_t n, double* out_dev, hipStream_t s);
 hipError_t lbh_launch_f64_to_f32(const double* in_dev, float* out_dev, int64_t n_elems, hipStream_t s);
 hipError_t lbh_launch_move_row(float* emb32, double* emb64, int64_t* created, uint64_t* tags, uint64_t* keys,
-                               int64_t dst, int64_t src, hipStream_t s);
+                               uint64_t* order, int64_t dst, int64_t src, hipStream_t s);
+hipError_t lbh_launch_iota_u64(uint64_t* dst, uint64_t first, int64_t n, hipStream_t s);
+hipError_t lbh_launch_scatter_u64(uint64_t* dst, const int64_t* rows_dev, const uint64_t* vals_dev, int64_t n, hipStream_t s);
 // search.hip
 int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu);
 hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
@@ -108,6 +136,9 @@ hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace&
                                    const lbh_qarg& qa, int k, int has_since,
                                    int64_t since_ms, uint64_t tag_mask, const lbh_cursor& cur, int grid, int seq,
                                    hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+hipError_t lbh_launch_recent(const int64_t* created, const uint64_t* order, int64_t n, const lbh_workspace& ws,
+                             int page, int has_since, int64_t since_ms, const lbh_rcursor& cur, int64_t anchor_row,
+                             int n_cu, int seq, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspace& ws, int nq, int k, int has_since,
                                      int64_t since_ms, uint64_t tag_mask, int n_cu, hipStream_t s, hipEvent_t ev0,
                                      hipEvent_t ev1);

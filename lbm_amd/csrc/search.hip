@@ -912,7 +912,305 @@ __global__ __launch_bounds__(SEL_THREADS) void select_exact_kernel(lbh_dev_index
     publish_result(res, seq);
 }
 
+// ------------------------------------------------------------------------------------------------
+// N3: recency query (get_recent_claims, lb/node.py:736-762): live rows with created_ms >= since_ms,
+// newest first.  The reference sorts with list.sort(key=created_ms, reverse=True), which is stable:
+// claims that share a timestamp keep the claims dict's insertion order, i.e. ascending `order`.
+// With a = created_ms ^ signbit and b = ~order the answer is the top-`page` of UNIQUE 128-bit keys
+// (a, b) in descending order -- integer work, no tolerance anywhere.
+//
+// recent_scan_kernel streams created[] once (8 B/row, 16-byte loads, 1024 rows per wave step) from the
+// END of the index backwards: rows are appended in publish order, so the newest claims come first, the
+// per-wave threshold (its page-th best key so far) is tight after the first step and order[] is only
+// read for rows that reach that threshold.  Each block emits its best <= page entries to a flat array;
+// recent_select_kernel (one block) cuts that array to the global top-page and sorts it.
+// ------------------------------------------------------------------------------------------------
+constexpr int RC_WCAP = 256;    // per-wave candidate buffer: <= 128 kept + one 128-row group
+constexpr int RC_GROUPS = 8;    // 128-row groups per wave step: 8 x 16-byte loads in flight per lane
+constexpr int RC_STEP = RC_GROUPS * 128;
+
+__device__ __forceinline__ bool rc_before(uint64_t a1, uint64_t b1, uint32_t r1, uint64_t a2, uint64_t b2, uint32_t r2) {
+    if (a1 != a2) return a1 > a2;
+    if (b1 != b2) return b1 > b2;
+    return r1 < r2;  // only padding (row = PAD_ROW) can tie on (a, b); it sorts last
+}
+
+template <class Sync>
+__device__ __forceinline__ void sort_recent(uint64_t* sa, uint64_t* sb, uint32_t* sr, int n, int tid, int nthreads, Sync sync) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n >> 1); t += nthreads) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool fwd = (i & k) == 0;
+                const uint64_t a1 = sa[i], a2 = sa[l], b1 = sb[i], b2 = sb[l];
+                const uint32_t r1 = sr[i], r2 = sr[l];
+                const bool swap = fwd ? rc_before(a2, b2, r2, a1, b1, r1) : rc_before(a1, b1, r1, a2, b2, r2);
+                if (swap) { sa[i] = a2; sa[l] = a1; sb[i] = b2; sb[l] = b1; sr[i] = r2; sr[l] = r1; }
+            }
+            sync();
+        }
+    }
+}
+
+typedef long long i64x2 __attribute__((ext_vector_type(2)));
+
+// Threshold seed: the page-th best key inside a 256-row window is a valid lower bound of the global
+// page-th best (a subset's k-th best never exceeds the whole set's).  The window sits where the next
+// results are expected when claims were appended in time order: at the end of the index for the first
+// page, just below the previous page's rows afterwards.  With a seed the scan admits only the handful of
+// rows that can matter, so no wave spends time sorting candidates it will throw away; on corpora in any
+// other order the seed is merely loose.  seed[0] = 1 when set, seed[1..2] = (a, b) admitted INCLUSIVELY.
+__global__ __launch_bounds__(256) void recent_seed_kernel(const int64_t* __restrict__ created,
+                                                           const uint64_t* __restrict__ order, int64_t n, int has_since,
+                                                           int64_t since_ms, lbh_rcursor cur, int page, int64_t w0,
+                                                           uint64_t* __restrict__ seed) {
+    __shared__ uint64_t sa[256], sb[256];
+    __shared__ int sv[256];
+    constexpr uint64_t SIGN = 0x8000000000000000ull;
+    const int tid = threadIdx.x;
+    const int64_t row = w0 + tid;
+    bool valid = row >= 0 && row < n;
+    uint64_t a = 0, b = 0;
+    if (valid) {
+        const int64_t c = created[row];
+        a = (uint64_t)c ^ SIGN;
+        b = ~order[row];
+        if (has_since && c < since_ms) valid = false;
+        if (cur.active && !(a < cur.a || (a == cur.a && b < cur.b))) valid = false;
+    }
+    sa[tid] = a;
+    sb[tid] = b;
+    sv[tid] = valid;
+    if (tid == 0) seed[0] = 0;
+    __syncthreads();
+    if (!valid) return;
+    int better = 0;
+    for (int i = 0; i < 256; ++i) better += (sv[i] && (sa[i] > a || (sa[i] == a && sb[i] > b))) ? 1 : 0;
+    if (better == page - 1) {  // keys are unique: exactly one thread, and only if the window holds >= page rows
+        seed[1] = a;
+        seed[2] = b;
+        __threadfence();
+        seed[0] = 1;
+    }
+}
+
+template <bool SINCE>
+__global__ __launch_bounds__(LBH_SCAN_THREADS) void recent_scan_kernel(const int64_t* __restrict__ created,
+                                                                        const uint64_t* __restrict__ order, int64_t n,
+                                                                        int64_t since_ms, lbh_rcursor cur, int page,
+                                                                        uint64_t* __restrict__ ca, uint64_t* __restrict__ cb,
+                                                                        uint32_t* __restrict__ crow,
+                                                                        unsigned long long* __restrict__ counters,
+                                                                        const uint64_t* __restrict__ seed) {
+    __shared__ uint64_t wa[LBH_SCAN_WAVES][RC_WCAP], wb[LBH_SCAN_WAVES][RC_WCAP];
+    __shared__ uint32_t wr[LBH_SCAN_WAVES][RC_WCAP];
+    __shared__ uint64_t ma[LBH_SCAN_WAVES * LBH_MAX_PAGE], mb[LBH_SCAN_WAVES * LBH_MAX_PAGE];
+    __shared__ uint32_t mr[LBH_SCAN_WAVES * LBH_MAX_PAGE];
+    __shared__ int wcnt[LBH_SCAN_WAVES];
+    __shared__ unsigned long long sh_match;
+    __shared__ int gbase;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    constexpr uint64_t SIGN = 0x8000000000000000ull;
+    uint64_t* A = wa[wave];
+    uint64_t* B = wb[wave];
+    uint32_t* R = wr[wave];
+    if (threadIdx.x == 0) sh_match = 0;
+    __syncthreads();
+
+    bool have_thr = false;
+    uint64_t ta = 0, tb = 0;  // the wave's page-th best key so far: only strictly better keys are kept
+    if (seed[0]) {            // start from the seed; it is inclusive, so step one key below it
+        const uint64_t s_a = seed[1], s_b = seed[2];
+        if (s_b != 0) { have_thr = true; ta = s_a; tb = s_b - 1; }
+        else if (s_a != 0) { have_thr = true; ta = s_a - 1; tb = ~0ull; }
+    }
+    int cnt = 0;
+    unsigned long long nmatch = 0;
+    const int64_t n_tiles = (n + RC_STEP - 1) / RC_STEP;
+
+    auto compact = [&]() {
+        const int n2 = pow2_at_least(cnt, 64);
+        for (int i = cnt + lane; i < n2; i += 64) { A[i] = 0; B[i] = 0; R[i] = PAD_ROW; }
+        __builtin_amdgcn_wave_barrier();
+        sort_recent(A, B, R, n2, lane, 64, WaveSync());
+        if (cnt >= page) {  // never below the seed: a wave's own page-th best is at least as good
+            cnt = page;
+            ta = A[page - 1];
+            tb = B[page - 1];
+            have_thr = true;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (int64_t t = (int64_t)blockIdx.x * LBH_SCAN_WAVES + wave; t < n_tiles; t += (int64_t)gridDim.x * LBH_SCAN_WAVES) {
+        const int64_t base = (n_tiles - 1 - t) * RC_STEP;
+        int64_t cr[RC_GROUPS][2];
+        if (base + RC_STEP <= n) {
+#pragma unroll
+            for (int j = 0; j < RC_GROUPS; ++j) {
+                const i64x2 v = *reinterpret_cast<const i64x2*>(created + base + j * 128 + 2 * lane);
+                cr[j][0] = v.x;
+                cr[j][1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RC_GROUPS; ++j) {
+                const int64_t r = base + j * 128 + 2 * lane;
+                cr[j][0] = r < n ? created[r] : 0;
+                cr[j][1] = r + 1 < n ? created[r + 1] : 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RC_GROUPS; ++j) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t row = base + j * 128 + 2 * lane + h;
+                const int64_t c = cr[j][h];
+                bool valid = row < n;
+                if (SINCE) valid = valid && c >= since_ms;
+                nmatch += valid ? 1u : 0u;
+                const uint64_t a = (uint64_t)c ^ SIGN;
+                const bool maybe = valid && (!have_thr || a >= ta) && (!cur.active || a <= cur.a);
+                uint64_t b = 0;
+                if (maybe) b = ~order[row];
+                const bool pass = maybe && (!have_thr || a > ta || b > tb) && (!cur.active || a < cur.a || b < cur.b);
+                const uint64_t m = __ballot(pass);
+                if (m) {
+                    if (pass) {
+                        const int pos = cnt + __popcll(m & lt_mask);
+                        A[pos] = a;
+                        B[pos] = b;
+                        R[pos] = (uint32_t)row;
+                    }
+                    cnt += __popcll(m);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (cnt > RC_WCAP - 128) compact();
+        }
+    }
+    if (cnt > 0) compact();
+    if (nmatch) atomicAdd(&sh_match, nmatch);
+    if (lane == 0) wcnt[wave] = cnt;
+    __syncthreads();
+
+    int off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < LBH_SCAN_WAVES; ++w) {
+        if (w < wave) off += wcnt[w];
+        total += wcnt[w];
+    }
+    if (threadIdx.x == 0 && sh_match) atomicAdd(&counters[1], sh_match);
+    if (total == 0) return;
+    for (int i = lane; i < cnt; i += 64) { ma[off + i] = A[i]; mb[off + i] = B[i]; mr[off + i] = R[i]; }
+    const int n2 = pow2_at_least(total, 2);
+    for (int i = total + threadIdx.x; i < n2; i += LBH_SCAN_THREADS) { ma[i] = 0; mb[i] = 0; mr[i] = PAD_ROW; }
+    __syncthreads();
+    sort_recent(ma, mb, mr, n2, threadIdx.x, LBH_SCAN_THREADS, BlockSync());
+    const int ns = total < page ? total : page;
+    if (threadIdx.x == 0) gbase = (int)atomicAdd(&counters[0], (unsigned long long)ns);
+    __syncthreads();
+    const int gb = gbase;
+    for (int i = threadIdx.x; i < ns; i += LBH_SCAN_THREADS) { ca[gb + i] = ma[i]; cb[gb + i] = mb[i]; crow[gb + i] = mr[i]; }
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void recent_select_kernel(int page, const uint64_t* __restrict__ ca,
+                                                                     const uint64_t* __restrict__ cb,
+                                                                     const uint32_t* __restrict__ crow,
+                                                                     unsigned long long* __restrict__ counters,
+                                                                     lbh_recent_result* __restrict__ res, int seq) {
+    __shared__ uint64_t sa[LBH_MCAP], sb[LBH_MCAP];
+    __shared__ uint32_t sr[LBH_MCAP];
+    __shared__ int hist[256];
+    __shared__ int64_t sh_krem;
+    __shared__ int sh_bin, sh_cnt, sh_gt, sh_eq;
+    const int tid = threadIdx.x;
+    constexpr uint64_t SIGN = 0x8000000000000000ull;
+    const int E = (int)counters[0];
+    const unsigned long long matched = counters[1];
+    if (tid == 0) { sh_cnt = 0; sh_gt = 0; sh_eq = 0; }
+    __syncthreads();
+    if (tid < 2) counters[tid] = 0;  // ready for the next launch
+
+    uint64_t T = 0, U = 0;
+    bool cut_b = false;
+    if (E > LBH_MCAP) {
+        auto val = [&](int e, uint64_t* v) { *v = ca[e]; return true; };
+        T = block_radix_select(E, 8, page, val, hist, &sh_krem, &sh_bin);
+        int gt = 0, eq = 0;
+        for (int e = tid; e < E; e += SEL_THREADS) {
+            const uint64_t a = ca[e];
+            gt += a > T;
+            eq += a == T;
+        }
+        if (gt) atomicAdd(&sh_gt, gt);
+        if (eq) atomicAdd(&sh_eq, eq);
+        __syncthreads();
+        if (sh_gt + sh_eq > LBH_MCAP) {  // mass tie on the page-th timestamp: cut the tie group by insertion order
+            const int64_t need = page - sh_gt;
+            auto bval = [&](int e, uint64_t* v) {
+                if (ca[e] != T) return false;
+                *v = cb[e];
+                return true;
+            };
+            U = block_radix_select(E, 8, need, bval, hist, &sh_krem, &sh_bin);
+            cut_b = true;
+        }
+    }
+    for (int e = tid; e < E; e += SEL_THREADS) {
+        const uint64_t a = ca[e], b = cb[e];
+        bool in = a >= T;
+        if (in && cut_b && a == T) in = b >= U;
+        if (in) {
+            const int pos = atomicAdd(&sh_cnt, 1);
+            if (pos < LBH_MCAP) { sa[pos] = a; sb[pos] = b; sr[pos] = crow[e]; }
+        }
+    }
+    __syncthreads();
+    const int M = sh_cnt < LBH_MCAP ? sh_cnt : LBH_MCAP;  // (a, b) is unique, so sh_cnt <= LBH_MCAP by construction
+    const int n2 = pow2_at_least(M, 2);
+    for (int j = M + tid; j < n2; j += SEL_THREADS) { sa[j] = 0; sb[j] = 0; sr[j] = PAD_ROW; }
+    __syncthreads();
+    sort_recent(sa, sb, sr, n2, tid, SEL_THREADS, BlockSync());
+    const int cnt = M < page ? M : page;
+    if (tid < cnt) {
+        res->rows[tid] = sr[tid];
+        res->created[tid] = (int64_t)(sa[tid] ^ SIGN);
+        res->order[tid] = ~sb[tid];
+    }
+    if (tid == 0) { res->count = cnt; res->matched = (int64_t)matched; }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&res->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
+
+hipError_t lbh_launch_recent(const int64_t* created, const uint64_t* order, int64_t n, const lbh_workspace& ws,
+                             int page, int has_since, int64_t since_ms, const lbh_rcursor& cur, int64_t anchor_row,
+                             int n_cu, int seq, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    const int64_t steps = (n + RC_STEP - 1) / RC_STEP;
+    int64_t blocks = (steps + LBH_SCAN_WAVES - 1) / LBH_SCAN_WAVES;
+    const int64_t cap = 2 * (int64_t)n_cu < LBH_RC_MAX_BLOCKS ? 2 * (int64_t)n_cu : LBH_RC_MAX_BLOCKS;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    uint64_t* seed = reinterpret_cast<uint64_t*>(ws.rc_cnt) + 4;
+    int64_t w0 = (anchor_row < n ? anchor_row : n) - 192;  // 192 rows below the anchor, 64 above
+    if (w0 + 256 > n) w0 = n - 256;
+    recent_seed_kernel<<<1, 256, 0, s>>>(created, order, n, has_since, since_ms, cur, page, w0, seed);
+    if (ev0) (void)hipEventRecord(ev0, s);
+    const dim3 g((unsigned)blocks), b(LBH_SCAN_THREADS);
+    if (has_since) recent_scan_kernel<true><<<g, b, 0, s>>>(created, order, n, since_ms, cur, page, ws.rc_a, ws.rc_b, ws.rc_row, ws.rc_cnt, seed);
+    else recent_scan_kernel<false><<<g, b, 0, s>>>(created, order, n, since_ms, cur, page, ws.rc_a, ws.rc_b, ws.rc_row, ws.rc_cnt, seed);
+    if (ev1) (void)hipEventRecord(ev1, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    recent_select_kernel<<<1, SEL_THREADS, 0, s>>>(page, ws.rc_a, ws.rc_b, ws.rc_row, ws.rc_cnt, ws.rc_result_dev, seq);
+    return hipGetLastError();
+}
 
 int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu) {
     const int64_t tiles = (n_rows + 63) / 64;

@@ -8,7 +8,7 @@ raises ``NodeError``, otherwise exactly ``graph.compile(...)`` -- is testable he
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Tuple
+from typing import Any, Dict, List, Optional, Tuple
 
 from .context_graph import ContextGraph
 
@@ -44,3 +44,21 @@ class RetrievalNode:
         g = self._require_group(group_id)
         slice_text, chosen = g.graph.compile(query, top_k=top_k, since_ms=since_ms)
         return slice_text, chosen
+
+    def get_recent_claims(self, group_id: str, since_ms: int, *, limit: int = 100) -> List[Dict[str, Any]]:
+        """lb/node.py:736-762: claims created at or after ``since_ms``, newest first, at most ``limit``.
+        The filter + sort + cut run on the GPU (``ContextGraph.recent``); only the chosen claims are
+        turned into dicts here."""
+        g = self._require_group(group_id)
+        claims = g.graph.claims
+        out = []
+        for h in g.graph.recent(since_ms, limit):
+            c = claims[h]
+            out.append({
+                "claim_hash": h,
+                "text": c.text,
+                "tags": list(c.tags),
+                "created_ms": c.created_ms,
+                "parent_hash": c.parent_hash,
+            })
+        return out

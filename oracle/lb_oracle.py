@@ -246,6 +246,32 @@ class OracleGraph:
         return [hashes[i] for i in idx], [float(s) for s in sc]
 
 
+def recent_claims(claims: Dict[str, "OracleClaim"], since_ms, limit=100) -> List[Dict[str, object]]:
+    """Restatement of BatteryNode.get_recent_claims, lb/node.py:750-762 (lb/node.py itself does not import
+    here: its `cryptography` dependency is absent, so this function is pinned by the expectations of the
+    reference's own tests -- tests/test_edge_cases.py:560-598, tests/test_multi_agent.py:170-193 -- which
+    tests/test_recent.py replays, not by generated golden vectors)."""
+    out = []
+    for h, c in claims.items():  # :751
+        if not c.retracted and c.created_ms >= since_ms:  # :752
+            out.append({"claim_hash": h, "text": c.text, "tags": list(c.tags), "created_ms": c.created_ms,
+                        "parent_hash": c.parent_hash})
+    out.sort(key=lambda x: x["created_ms"], reverse=True)  # :761 (stable: ties keep dict order)
+    return out[:limit]  # :762
+
+
+def recent_arrays(created_ms: np.ndarray, order: np.ndarray, since_ms: int, limit: int) -> np.ndarray:
+    """Array form of the same ordering for large cases: indices of rows with created_ms >= since_ms sorted by
+    (created_ms descending, order ascending), cut to `limit` (>= 0)."""
+    created_ms = np.asarray(created_ms, dtype=np.int64)
+    idx = np.nonzero(created_ms >= since_ms)[0]
+    # (created desc, order asc) without negating int64 (INT64_MIN has no negative): two stable sorts
+    by_order = idx[np.argsort(np.asarray(order, dtype=np.uint64)[idx], kind="stable")]
+    rev = by_order[::-1]                                  # order descending
+    asc = rev[np.argsort(created_ms[rev], kind="stable")]  # created ascending, ties in order DESCENDING
+    return asc[::-1][:max(0, int(limit))]                  # created descending, ties in order ascending
+
+
 def format_context(query: str, chosen_claims) -> str:
     """lb/context_graph.py:122-133."""
     lines = ["Context slice", f"Query: {query}", ""]

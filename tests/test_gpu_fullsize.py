@@ -139,3 +139,25 @@ def test_first_million_against_oracle(corpus):
     got_i, got_s, _ = ix.search_shard(q[0], 64, int(ms[600_000]), 0xFF)
     assert got_i.tolist() == want_i.tolist() and got_s.tobytes() == want_s.tobytes()
     ix.close()
+
+
+def test_recent_10m(corpus):
+    """N3 at full size: created_ms is strictly increasing with the claim id in this corpus, so the newest-first
+    answer is known in closed form; `matched` must count exactly the rows at or after the bound."""
+    hip, ix = corpus["hip"], corpus["ix"]
+    st = hip.Stats()
+    base = 1_700_000_000_000
+    for since, limit in [(hip.SINCE_NONE, 8), (hip.SINCE_NONE, 200), (base + 1000 * (N_FULL - 150), 1000), (base + 1000 * 5_000_000, 64)]:
+        ids, created, matched = ix.recent(since, limit, st)
+        first = 0 if since == hip.SINCE_NONE else (since - base + 999) // 1000
+        exp_matched = N_FULL - first
+        take = min(limit, exp_matched)
+        assert matched == exp_matched
+        assert ids.tolist() == list(range(N_FULL - 1, N_FULL - 1 - take, -1))
+        assert created.tolist() == [base + 1000 * i for i in range(N_FULL - 1, N_FULL - 1 - take, -1)]
+        assert st.path == 3 and st.rows_scanned == N_FULL
+    # the two half-corpus shards hold the rows round-robin: merging their answers by (created desc) gives the same list
+    a, ca, _ = corpus["half"][0].recent(hip.SINCE_NONE, 64)
+    b, cb, _ = corpus["half"][1].recent(hip.SINCE_NONE, 64)
+    merged = sorted(ca.tolist() + cb.tolist(), reverse=True)[:64]
+    assert merged == [base + 1000 * i for i in range(N_FULL - 1, N_FULL - 65, -1)]

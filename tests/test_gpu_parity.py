@@ -170,6 +170,79 @@ def test_cache_view_and_direct_mutation_semantics(hip):
     assert g.compile("changed") == og.compile("changed") == ("Context slice\nQuery: changed\n", [])
 
 
+@pytest.mark.parametrize("seed,hex_hashes", [(11, True), (12, False), (13, True)])
+def test_randomised_incremental_ops_vs_oracle(hip, seed, hex_hashes):
+    """publish / overwrite / retract / direct edits interleaved with queries.  The device
+    mirror is updated incrementally (appends, swap-deletes, metadata pokes); after every mutation burst the
+    ranking, scores and context text must equal the reference semantics (oracle graph, pinned by golden)."""
+    import hashlib
+    import random
+    from lbm_amd.context_graph import ContextGraph
+    rnd = random.Random(seed)
+    vocab = ["alpha", "beta", "gamma", "delta", "eps", "zeta", "eta", "theta", "iota", "kappa", "lam", "mu",
+             "nu", "xi", "omi", "pi", "rho", "sigma", "tau", "ups", "phi", "chi", "psi", "omega", "x1", "y_2"]
+    tags_pool = ["a", "b", "c", "d"]
+    g, og = ContextGraph(), orc.OracleGraph()
+    known = []
+    counter = 0
+
+    def new_hash():
+        nonlocal counter
+        counter += 1
+        if hex_hashes:
+            return hashlib.sha256(b"claim%d-%d" % (seed, counter)).hexdigest()
+        return rnd.choice(["z", "A", "m", "0", "~"]) * rnd.randint(1, 3) + "-%d" % rnd.randint(0, 10 ** 6) + "/%d" % counter
+
+    def text():
+        return " ".join(rnd.choice(vocab) for _ in range(rnd.randint(0, 6)))
+
+    n_queries = 0
+    for step in range(700):
+        r = rnd.random()
+        if r < 0.45 or not known:
+            h = new_hash()
+            args = (h, text(), rnd.sample(tags_pool, rnd.randint(0, 2)))
+            ms = rnd.randint(0, 50)
+            g.add_claim(*args, created_ms=ms); og.add_claim(*args, created_ms=ms)
+            known.append(h)
+        elif r < 0.55:
+            h = rnd.choice(known)
+            args = (h, text(), [])
+            ms = rnd.randint(0, 50)
+            g.add_claim(*args, created_ms=ms); og.add_claim(*args, created_ms=ms)
+        elif r < 0.68:
+            h = rnd.choice(known)
+            g.retract(h); og.retract(h)
+        elif r < 0.70:
+            g.retract("never-added"); og.retract("never-added")
+        elif r < 0.73:
+            h = rnd.choice(known)
+            if h in og.claims:
+                flag = not og.claims[h].retracted
+                g.claims[h].retracted = flag; og.claims[h].retracted = flag
+        elif r < 0.76:
+            h = rnd.choice(known)
+            if h in og.claims:
+                ms = rnd.randint(0, 50)
+                g.claims[h].created_ms = ms; og.claims[h].created_ms = ms
+        elif r < 0.78:
+            h = rnd.choice(known)
+            if h in og.claims:
+                del g.claims[h]; del og.claims[h]
+                known.remove(h)
+        else:
+            q = " ".join(rnd.choice(vocab) for _ in range(rnd.randint(0, 3)))
+            kw = {"top_k": rnd.choice([0, 1, 3, 8, 8, 8, 20, 100])}
+            if rnd.random() < 0.4:
+                kw["since_ms"] = rnd.randint(0, 55)
+            assert g.compile(q, **kw) == og.compile(q, **kw), (step, q, kw)
+            hs, sc = g.compile_scored(q, **kw)
+            ohs, osc = og.compile_scored(q, **kw)
+            assert hs == ohs and hexes(sc) == hexes(osc), (step, q, kw)
+            n_queries += 1
+    assert n_queries > 100
+
+
 def _arrays_case(n, seed, dup_frac=0.002):
     from lbm_amd import synth
     ch = synth.make_chunk(0, n, seed=seed, real_sha_keys=False, dup_frac=dup_frac)
