@@ -141,6 +141,12 @@ int lbh_index_search_shard(lbh_index* idx, const double* q_f64, int64_t k, int64
                            uint64_t* out_ids, double* out_scores, uint8_t* out_keys, int64_t* out_count,
                            lbh_stats* stats);
 
+/* Merge step of the claim-sharded search (host code, needs no GPU): `lists` = n_lists blocks of (k + 1) x 6
+ * int64, as exchanged by the all-gather -- row 0 word 0 = entry count (<= k), rows 1.. = {fp64 score bits,
+ * global claim id, 4 big-endian key words}.  Writes the global top-k entries (6 words each) in the
+ * reference's order (lb/context_graph.py:120: score descending, hash key ascending) to out_entries. */
+int lbh_merge_topk(const int64_t* lists, int64_t n_lists, int64_t k, int64_t* out_entries, int64_t* out_count);
+
 /* ---- next row N3: recency query ------------------------------ */
 
 /* replaces the loop + sort + slice of BatteryNode.get_recent_claims (lb/node.py:750-762): live claims

@@ -32,7 +32,7 @@ EXPORTS = [
     "lbh_index_create", "lbh_index_destroy", "lbh_index_reserve", "lbh_index_add", "lbh_index_retract",
     "lbh_index_update_meta", "lbh_index_set_keys", "lbh_index_size", "lbh_index_get_embedding",
     "lbh_index_search", "lbh_index_search_text", "lbh_index_search_shard",
-    "lbh_index_recent", "lbh_index_set_order",
+    "lbh_index_recent", "lbh_index_set_order", "lbh_merge_topk",
 ]
 
 
@@ -126,6 +126,7 @@ def load_library() -> ctypes.CDLL:
         L.lbh_index_recent.argtypes = [_vp, _i64, _i64, _vp, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64),
                                        ctypes.POINTER(Stats)]
         L.lbh_index_set_order.argtypes = [_vp, _i64, _vp, _vp]
+        L.lbh_merge_topk.argtypes = [_vp, _i64, _i64, _vp, ctypes.POINTER(_i64)]
         L.lbh_index_search_shard.argtypes = [_vp, _vp, _i64, _i64, _u64, _vp, _vp, _vp, ctypes.POINTER(_i64),
                                              ctypes.POINTER(Stats)]
         for name in EXPORTS:
@@ -166,6 +167,18 @@ def context():
 
 def set_option(name: str, value: int) -> None:
     _check(load_library().lbh_set_option(context(), name.encode(), int(value)))
+
+
+def merge_topk(lists: np.ndarray, k: int) -> np.ndarray:
+    """lists: int64 [n_lists, k + 1, 6] (sharded.pack_local layout) -> int64 [m, 6], the global top-k entries."""
+    lists = np.ascontiguousarray(lists, dtype=np.int64)
+    k = int(k)
+    if lists.ndim != 3 or lists.shape[1] != k + 1 or lists.shape[2] != 6:
+        raise ValueError("lists must have shape [n_lists, k + 1, 6]")
+    out = np.empty((max(k, 1), 6), dtype=np.int64)
+    cnt = _i64(0)
+    _check(load_library().lbh_merge_topk(_ptr(lists), lists.shape[0], k, _ptr(out), ctypes.byref(cnt)))
+    return out[:cnt.value]
 
 
 def device_name() -> str:

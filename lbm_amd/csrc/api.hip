@@ -711,6 +711,38 @@ int lbh_index_recent(lbh_index* ix, int64_t since_ms, int64_t limit, uint64_t* o
     return LBH_OK;
 }
 
+int lbh_merge_topk(const int64_t* lists, int64_t n_lists, int64_t k, int64_t* out_entries, int64_t* out_count) {
+    if (n_lists < 0 || k < 0 || (n_lists > 0 && !lists) || !out_count || (k > 0 && !out_entries))
+        return fail(LBH_E_INVALID, "bad argument");
+    struct Ref { double s; const int64_t* e; };
+    std::vector<Ref> all;
+    all.reserve((size_t)(n_lists * k));
+    for (int64_t l = 0; l < n_lists; ++l) {
+        const int64_t* base = lists + l * (k + 1) * 6;
+        const int64_t cnt = base[0];
+        if (cnt < 0 || cnt > k) return fail(LBH_E_INVALID, "list %lld announces %lld entries, k = %lld", (long long)l, (long long)cnt, (long long)k);
+        for (int64_t i = 1; i <= cnt; ++i) {
+            double sc;
+            memcpy(&sc, base + i * 6, 8);
+            all.push_back({sc, base + i * 6});
+        }
+    }
+    // lb/context_graph.py:120: score descending (-0.0 == 0.0, as in Python), then hash ascending
+    auto before = [](const Ref& a, const Ref& b) {
+        if (a.s != b.s) return a.s > b.s;
+        for (int w = 2; w < 6; ++w) {
+            const uint64_t x = (uint64_t)a.e[w], y = (uint64_t)b.e[w];
+            if (x != y) return x < y;
+        }
+        return false;
+    };
+    const size_t take = std::min<size_t>((size_t)k, all.size());
+    std::partial_sort(all.begin(), all.begin() + take, all.end(), before);
+    for (size_t i = 0; i < take; ++i) memcpy(out_entries + i * 6, all[i].e, 48);
+    *out_count = (int64_t)take;
+    return LBH_OK;
+}
+
 int lbh_index_size(lbh_index* ix, int64_t* out_live) {
     if (!ix || !out_live) return fail(LBH_E_INVALID, "bad argument");
     std::lock_guard<std::mutex> lk(ix->mu);

@@ -50,33 +50,72 @@ def merge_gathered(gathered: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray
     return e[order, 1].copy().view(np.uint64), scores[order], kw[order]
 
 
+def merge_entries(gathered: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Same result as ``merge_gathered`` through the C ABI's host merge (``lbh_merge_topk``, a partial sort
+    of the k*N entries in C instead of five numpy passes)."""
+    from . import _hip
+    e = _hip.merge_topk(gathered, k)
+    return (e[:, 1].copy().view(np.uint64), e[:, 0].copy().view(np.float64),
+            np.ascontiguousarray(e[:, 2:6]).view(np.uint64))
+
+
+class _Buffers:
+    """Exchange buffers for one k: pinned staging on both sides of the collective, allocated once."""
+
+    def __init__(self, k: int, world: int, device) -> None:
+        import torch
+        rows = k + 1
+        on_gpu = device is not None and torch.device(device).type == "cuda"
+        self.send_host = torch.zeros((rows, ENTRY_WORDS), dtype=torch.int64, pin_memory=on_gpu)
+        self.recv_host = torch.zeros((world * rows, ENTRY_WORDS), dtype=torch.int64, pin_memory=on_gpu)
+        self.send_np = self.send_host.numpy()
+        self.recv_np = self.recv_host.numpy().reshape(world, rows, ENTRY_WORDS)
+        if on_gpu:
+            self.send_dev = torch.zeros((rows, ENTRY_WORDS), dtype=torch.int64, device=device)
+            self.recv_dev = torch.zeros((world * rows, ENTRY_WORDS), dtype=torch.int64, device=device)
+        else:  # gloo on CPU tensors (tests)
+            self.send_dev, self.recv_dev = self.send_host, self.recv_host
+        self.on_gpu = on_gpu
+
+
 class ShardedSearcher:
     """Wraps a rank-local search function with the all-gather merge.
 
     ``local_search(q, k, since_ms, tag_mask) -> (local_ids, scores, keys[n, 32])`` is normally
     ``lbm_amd._hip.Index.search_shard``.  ``gid_of_local`` maps local claim ids to global ones
     (default: ``local_id * world + rank``, i.e. claims dealt round-robin to ranks).
+
+    Per query: pack k entries into pinned memory, one async H2D copy, ONE ``all_gather_into_tensor``
+    (RCCL over xGMI under backend "nccl"), one async D2H copy into pinned memory, one stream
+    synchronisation, then the host merge of the k*N entries.
     """
 
     def __init__(self, local_search: Callable, rank: int, world: int, *, device=None, group=None,
                  gid_of_local: Optional[Callable[[np.ndarray], np.ndarray]] = None,
-                 always_gather: bool = False) -> None:
+                 always_gather: bool = False, c_merge: bool = True) -> None:
         self.local_search, self.rank, self.world = local_search, rank, world
         self.device, self.group = device, group
         self.always_gather = always_gather  # run the collective even for world == 1 (tests)
         self.gid_of_local = gid_of_local or (lambda ids: ids.astype(np.uint64) * np.uint64(world) + np.uint64(rank))
+        self._merge = merge_entries if c_merge else merge_gathered
+        self._bufs = {}
 
     def search(self, q: np.ndarray, k: int, since_ms: int, tag_mask: int = 0):
         k = max(0, int(k))
         ids, scores, keys = self.local_search(q, k, since_ms, tag_mask)
         local = pack_local(scores, self.gid_of_local(np.asarray(ids)), keys, k)
         if self.world == 1 and not self.always_gather:
-            return merge_gathered(local[None], k)
+            return self._merge(local[None], k)
         import torch
         import torch.distributed as dist
-        t = torch.from_numpy(local)
-        if self.device is not None:
-            t = t.to(self.device, non_blocking=True)
-        out = torch.empty((self.world * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t, group=self.group)  # rank-major concatenation
-        return merge_gathered(out.cpu().numpy().reshape(self.world, t.shape[0], t.shape[1]), k)
+        b = self._bufs.get(k)
+        if b is None:
+            b = self._bufs[k] = _Buffers(k, self.world, self.device)
+        b.send_np[...] = local
+        if b.on_gpu:
+            b.send_dev.copy_(b.send_host, non_blocking=True)
+        dist.all_gather_into_tensor(b.recv_dev, b.send_dev, group=self.group)  # rank-major concatenation
+        if b.on_gpu:
+            b.recv_host.copy_(b.recv_dev, non_blocking=True)
+            torch.cuda.current_stream(b.recv_dev.device).synchronize()
+        return self._merge(b.recv_np, k)

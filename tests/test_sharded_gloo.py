@@ -70,8 +70,11 @@ def test_two_rank_allgather_merge_equals_single_corpus():
         assert all(a and b for a, b in results), (rank, results)
 
 
-def test_merge_orders_ties_by_key_and_handles_short_lists():
-    from lbm_amd.sharded import merge_gathered, pack_local
+@pytest.mark.parametrize("which", ["numpy", "c_abi"])
+def test_merge_orders_ties_by_key_and_handles_short_lists(which):
+    from lbm_amd import sharded
+    from lbm_amd.sharded import pack_local
+    merge_gathered = sharded.merge_gathered if which == "numpy" else sharded.merge_entries
     k = 4
     keys = np.zeros((3, 32), dtype=np.uint8)
     keys[0, 0], keys[1, 0], keys[2, 0] = 9, 1, 5
@@ -89,3 +92,23 @@ def test_merge_orders_ties_by_key_and_handles_short_lists():
     y = pack_local(np.array([0.0]), np.array([2], dtype=np.uint64), keys[1:2], k)
     ids, _, _ = merge_gathered(np.stack([z, y]), k)
     assert ids.tolist() == [2, 1]
+
+
+def test_c_merge_equals_numpy_merge_on_random_lists():
+    """lbh_merge_topk (host code of the C ABI) against the numpy merge: ties on score, short and empty lists."""
+    from lbm_amd.sharded import merge_entries, merge_gathered, pack_local
+    rng = np.random.default_rng(17)
+    for trial in range(60):
+        k = int(rng.choice([1, 3, 8, 64]))
+        world = int(rng.integers(1, 9))
+        lists = []
+        for r in range(world):
+            n = int(rng.integers(0, k + 1))
+            sc = np.sort(rng.choice([0.0, -0.0, 0.25, 0.5, 0.75, -0.5], size=n))[::-1].copy()
+            keys = rng.integers(0, 3, size=(n, 32), dtype=np.uint8)  # few distinct bytes: shared key prefixes
+            keys[:, 31] = rng.integers(0, 256, size=n)
+            lists.append(pack_local(sc, rng.integers(0, 2 ** 63, size=n).astype(np.uint64), keys, k))
+        g = np.stack(lists)
+        a, b = merge_gathered(g, k), merge_entries(g, k)
+        assert a[1].tobytes() == b[1].tobytes() or np.array_equal(a[1], b[1])  # scores (+-0.0 may differ in bits only on ties)
+        assert np.array_equal(a[2], b[2])  # key words: the order of the reference
