@@ -46,6 +46,7 @@ struct lbh_ctx {
     std::string arch;
     int scan_blocks_per_cu = 2;  // tuning knobs (env LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT), see DESIGN.md
     int scan_nt = 1;
+    int bq_bf16 = 1;     // batched scan: 1 = split-bf16 products (3 MFMAs at 16x the fp32 rate), 0 = exact fp32 MFMA
     int spin_us = 5000;  // poll the completion ticket this long before blocking in hipStreamSynchronize (0 = always block)
     std::mutex mu;  // serialises use of the scratch below
     // small scratch for embed / cosine calls
@@ -361,6 +362,7 @@ int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx) {
     c->arch = prop.gcnArchName;
     if (const char* e1 = getenv("LBH_SCAN_BLOCKS_PER_CU")) c->scan_blocks_per_cu = std::max(1, std::min(8, atoi(e1)));
     if (const char* e2 = getenv("LBH_SCAN_NT")) c->scan_nt = atoi(e2) != 0;
+    if (const char* e4 = getenv("LBH_BQ_BF16")) c->bq_bf16 = atoi(e4) != 0;
     if (const char* e3 = getenv("LBH_SPIN_US")) c->spin_us = std::max(0, std::min(1000000, atoi(e3)));
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -394,6 +396,7 @@ int lbh_set_option(lbh_ctx* c, const char* name, int64_t value) {
     std::lock_guard<std::mutex> lk(c->mu);
     if (!strcmp(name, "scan_blocks_per_cu")) c->scan_blocks_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "scan_nt")) c->scan_nt = value != 0;
+    else if (!strcmp(name, "bq_bf16")) c->bq_bf16 = value != 0;
     else if (!strcmp(name, "spin_us")) c->spin_us = (int)std::max<int64_t>(0, std::min<int64_t>(1000000, value));
     else return fail(LBH_E_INVALID, "unknown option %s", name);
     return LBH_OK;
@@ -786,7 +789,7 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
         for (int64_t q0 = 0; q0 < nq; q0 += LBH_BQ_MAXQ) {
             const int nb = (int)std::min<int64_t>(LBH_BQ_MAXQ, nq - q0);
             HIP_TRY(hipMemcpyAsync(ix->ws.bq_qmat, q_f64 + q0 * 64, (size_t)nb * 512, hipMemcpyHostToDevice, s));
-            HIP_TRY(lbh_launch_search_batched(dv, ix->ws, nb, (int)keff, has_since, since_ms, tag_mask, c->n_cu, s,
+            HIP_TRY(lbh_launch_search_batched(dv, ix->ws, nb, (int)keff, has_since, since_ms, tag_mask, c->n_cu, c->bq_bf16, s,
                                               timing ? c->ev[0] : nullptr, timing ? c->ev[1] : nullptr));
             HIP_TRY(hipStreamSynchronize(s));
             total.scan_launches += 1;

@@ -21,6 +21,11 @@
 // (input rounding 2*2^-24 + 64 fp32 roundings, DESIGN.md "Error bound"); candidates are every row
 // within 2*eps of the k-th best fp32 score, so the exact top-k is always among them.
 #define LBH_MARGIN 1.0e-5f
+// Batched scan with split-bf16 products (x = hi + lo, x*q ~ hi*hi + hi*lo + lo*hi): the dropped lo*lo term and
+// the split residues are < 3 * 2^-18 |x q| (1.2e-5 summed over a unit vector pair); 192 fp32 accumulations of
+// partial sums <= ~1 add at most 192 * 2^-23 = 2.3e-5 even if the matrix pipe truncated instead of rounding.
+// eps < 3.5e-5, margin = 1e-4 > 2 eps.  lbh_stats.max_score_err reports the largest error actually seen.
+#define LBH_MARGIN_BF16X3 1.0e-4f
 
 // ---- order-preserving integer images of floats ------------------------------------------------
 __host__ __device__ inline uint32_t lbh_ord32(float f) {
@@ -140,5 +145,5 @@ hipError_t lbh_launch_recent(const int64_t* created, const uint64_t* order, int6
                              int page, int has_since, int64_t since_ms, const lbh_rcursor& cur, int64_t anchor_row,
                              int n_cu, int seq, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspace& ws, int nq, int k, int has_since,
-                                     int64_t since_ms, uint64_t tag_mask, int n_cu, hipStream_t s, hipEvent_t ev0,
-                                     hipEvent_t ev1);
+                                     int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, hipStream_t s,
+                                     hipEvent_t ev0, hipEvent_t ev1);

@@ -358,7 +358,7 @@ __device__ void rerank_and_emit(uint64_t* xo, uint32_t* xr, int M, int k, const 
 // K4 body: global fp32 threshold over E flat candidates, candidate cut, exact fp64 re-rank.
 // `qs` (64 doubles in LDS) must be filled and a barrier passed before the call.
 __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int k, const uint64_t* __restrict__ cand,
-                                 int E, lbh_result* __restrict__ res) {
+                                 int E, lbh_result* __restrict__ res, float margin) {
     __shared__ uint64_t sbuf[2 * LBH_MCAP];      // 32 KB: entries, later (ord64 | rows)
     __shared__ int hist[256];
     __shared__ int64_t sh_krem;
@@ -374,7 +374,7 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
         for (int i = E + tid; i < n2; i += SEL_THREADS) sbuf[i] = 0;
         __syncthreads();
         sort_desc_u64(sbuf, n2, tid, SEL_THREADS, BlockSync());
-        if (E >= k) thr = lbh_ord32(lbh_unord32((uint32_t)(sbuf[k - 1] >> 32)) - LBH_MARGIN);
+        if (E >= k) thr = lbh_ord32(lbh_unord32((uint32_t)(sbuf[k - 1] >> 32)) - margin);
         for (int i = tid; i < E; i += SEL_THREADS) {
             const bool in = (uint32_t)(sbuf[i] >> 32) >= thr;
             const bool next_in = (i + 1 < E) && (uint32_t)(sbuf[i + 1] >> 32) >= thr;
@@ -389,7 +389,7 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
                 return true;
             };
             const uint32_t kth = (uint32_t)block_radix_select(E, 4, k, val, hist, &sh_krem, &sh_bin);
-            thr = lbh_ord32(lbh_unord32(kth) - LBH_MARGIN);
+            thr = lbh_ord32(lbh_unord32(kth) - margin);
         }
         for (int e = tid; e < E; e += SEL_THREADS) {
             const uint64_t v = cand[e];
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index 
     if (overflowed) {
         if (tid == 0) { res->count = 0; res->overflow = 1; res->candidates = 0; }
     } else {
-        select_fast_body(ix, qs, k, cand, E, res);
+        select_fast_body(ix, qs, k, cand, E, res, LBH_MARGIN);
     }
     publish_result(res, seq);
 }
@@ -494,6 +494,7 @@ struct bq_ctx {          // per-wave view of the K3 candidate state (LDS) for th
     int32_t* qtotal;
     int k, lane, wave, myq, h;
     bool qactive;
+    float margin;  // 2 x (error bound of the scan's scores): LBH_MARGIN for fp32 MFMA, LBH_MARGIN_BF16X3 for split bf16
 };
 
 // one query's buffer (<= 56 entries, one per lane): find the k-th largest by rank counting (entries are
@@ -512,7 +513,7 @@ __device__ __forceinline__ void bq_compact_impl(const bq_ctx& c, int q) {
         const uint64_t sel = __ballot(lane < cnt && rank == c.k - 1);
         const int src = __ffsll((long long)sel) - 1;
         const uint32_t kth = (uint32_t)(__shfl(v, src) >> 32);
-        const uint32_t nt = lbh_ord32(lbh_unord32(kth) - LBH_MARGIN);
+        const uint32_t nt = lbh_ord32(lbh_unord32(kth) - c.margin);
         if (nt > t2) t2 = nt;
         const bool keep = lane < cnt && (uint32_t)(v >> 32) >= t2;
         const uint64_t km = __ballot(keep);
@@ -532,10 +533,8 @@ __device__ __forceinline__ void bq_compact_impl(const bq_ctx& c, int q) {
 __device__ __noinline__ void bq_compact(const bq_ctx& c, int q) { bq_compact_impl(c, q); }
 
 // slow path of the K3 epilogue: exact ord compare, mask, append, compaction.  Returns the lane's
-// (possibly raised) threshold.  Two flavours: the main pass (thresholds seeded, a candidate is rare)
-// calls it OUT OF LINE so that it costs the MFMA loop no registers -- a call spills the caller's live
-// registers around it, which is fine when rare; the sample pass (cold thresholds: every tile has
-// candidates) inlines it, because there the spill traffic of a call per tile dominated everything.
+// (possibly raised) threshold.  Inlined into the scan loop: an out-of-line call spilled the caller's live
+// registers around every candidate tile, which dominated the cold sample pass.
 template <bool INL>
 __device__ __forceinline__ uint32_t bq_harvest_impl(const bq_ctx& c, const f32x16& acc, int64_t row0, uint32_t rowmask,
                                                     uint32_t thr) {
@@ -565,11 +564,10 @@ __device__ __forceinline__ uint32_t bq_harvest_impl(const bq_ctx& c, const f32x1
     }
     return thr;
 }
-__device__ __noinline__ uint32_t bq_harvest(const bq_ctx& c, f32x16 acc, int64_t row0, uint32_t rowmask, uint32_t thr) {
-    return bq_harvest_impl<false>(c, acc, row0, rowmask, thr);
-}
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <bool SINCE, bool TAGS, bool WARM>
+template <bool SINCE, bool TAGS, bool BF16>
 __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index ix, const double* __restrict__ qmat,
                                                                    int nq, int k, int64_t since_ms, uint64_t tag_mask,
                                                                    int64_t row_begin, int64_t row_end,
@@ -593,13 +591,30 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
 
     // seed: per-query lower bounds on the final threshold (k-th best of a sample pass - margin)
     if (tid < BQ_MAXQ) { qcnt[tid] = 0; qthr[tid] = (seed && tid < nq) ? seed[tid] : 0u; }
+    // B operand = this lane's query.  fp32 MFMA (32x32x2): dims 2s + h.  Split-bf16 MFMA (32x32x16): k-step s
+    // takes dims 16s + 8h + 0..7, each value as hi = bf16(v) and lo = bf16(v - hi).
     float b[32];
+    bf16x8 bh[4], bl[4];
+    if (!BF16) {
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-        // unconditional load from a clamped row, then select: a load under a lane-dependent branch would
-        // be waited for on the spot (32 serial round trips)
-        const float v = (float)qmat[(size_t)(qactive ? myq : 0) * 64 + 2 * s + h];
-        b[s] = qactive ? v : 0.f;
+        for (int s = 0; s < 32; ++s) {
+            // unconditional load from a clamped row, then select: a load under a lane-dependent branch would
+            // be waited for on the spot (32 serial round trips)
+            const float v = (float)qmat[(size_t)(qactive ? myq : 0) * 64 + 2 * s + h];
+            b[s] = qactive ? v : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v0 = (float)qmat[(size_t)(qactive ? myq : 0) * 64 + 16 * s + 8 * h + e];
+                const float v = qactive ? v0 : 0.f;
+                const __bf16 hi = (__bf16)v;
+                bh[s][e] = hi;
+                bl[s][e] = (__bf16)(v - (float)hi);
+            }
+        }
     }
     uint32_t thr = (seed && qactive) ? seed[myq] : 0u;
 
@@ -610,17 +625,31 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
         // would expose the HBM latency every super-tile; rows >= n are dropped by row_mask() instead
         int64_t r = row_begin + st * 64 + half * 32 + srow;
         r = r < n ? r : n - 1;
+#if LBH_BQ_ABLATE == 3  // timing-only build: no HBM traffic in the loop (every tile is the first one)
+        r = srow;
+#endif
         return __builtin_nontemporal_load(&E[r * 16 + sc4]);
     };
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto store_half = [&](int buf, int half, f32x4 v) {
-        float* d = tile + (size_t)buf * BQ_TILE_F + (half * 32 + srow) * BQ_TS + 2 * sc4;
-        *reinterpret_cast<f32x2*>(d) = f32x2{v.x, v.z};        // even dims 4c, 4c+2  -> slots 2c, 2c+1
-        *reinterpret_cast<f32x2*>(d + 32) = f32x2{v.y, v.w};   // odd dims            -> 32 + 2c, 32 + 2c+1
+        if (!BF16) {
+            float* d = tile + (size_t)buf * BQ_TILE_F + (half * 32 + srow) * BQ_TS + 2 * sc4;
+            *reinterpret_cast<f32x2*>(d) = f32x2{v.x, v.z};        // even dims 4c, 4c+2  -> slots 2c, 2c+1
+            *reinterpret_cast<f32x2*>(d + 32) = f32x2{v.y, v.w};   // odd dims            -> 32 + 2c, 32 + 2c+1
+        } else {
+            // same 272-byte rows: [64 x bf16 hi | 64 x bf16 lo | pad]; the split is done once here, by the
+            // staging thread, not by the eight waves that consume the tile
+            char* d = reinterpret_cast<char*>(tile + (size_t)buf * BQ_TILE_F + (half * 32 + srow) * BQ_TS) + 8 * sc4;
+            const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+            const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+            *reinterpret_cast<bf16x4*>(d) = hi;
+            *reinterpret_cast<bf16x4*>(d + 128) = lo;
+        }
     };
     bq_ctx bc;
     bc.qbuf = qbuf; bc.qcnt = qcnt; bc.qthr = qthr; bc.qtotal = qtotal;
     bc.k = k; bc.lane = lane; bc.wave = wave; bc.myq = myq; bc.h = h; bc.qactive = qactive;
+    bc.margin = BF16 ? LBH_MARGIN_BF16X3 : LBH_MARGIN;
     auto compact_query = [&](int q) { bq_compact(bc, q); };
 
     // rows of one 32-claim tile that pass the since / tag filters, as one word (lanes 0..31 vote)
@@ -637,8 +666,7 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
     // float image of thr: a cheap superset test in the common case (idle lanes never hit)
     float thr_f = qactive ? (thr ? lbh_unord32(thr) : -__builtin_inff()) : __builtin_inff();
     auto harvest = [&](const f32x16& acc, int64_t row0, uint32_t rowmask) {
-        if (WARM) thr = bq_harvest_impl<true>(bc, acc, row0, rowmask, thr);
-        else thr = bq_harvest(bc, acc, row0, rowmask, thr);
+        thr = bq_harvest_impl<true>(bc, acc, row0, rowmask, thr);  // inlined: a call per candidate tile spilled more than it saved
         if (qactive) thr_f = thr ? lbh_unord32(thr) : -__builtin_inff();
     };
     auto any_hit = [&](const f32x16& acc) -> bool {
@@ -654,14 +682,29 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
     const int64_t G = gridDim.x;
     int64_t st = blockIdx.x;
     float a0[32], a1[32];
+    bf16x8 a0h[4], a0l[4], a1h[4], a1l[4];
     auto read_frags = [&](int buf) {
-        const f32x4* p0 = reinterpret_cast<const f32x4*>(tile + (size_t)buf * BQ_TILE_F + j * BQ_TS + h * 32);
-        const f32x4* p1 = reinterpret_cast<const f32x4*>(tile + (size_t)buf * BQ_TILE_F + (32 + j) * BQ_TS + h * 32);
+        if (!BF16) {
+            const f32x4* p0 = reinterpret_cast<const f32x4*>(tile + (size_t)buf * BQ_TILE_F + j * BQ_TS + h * 32);
+            const f32x4* p1 = reinterpret_cast<const f32x4*>(tile + (size_t)buf * BQ_TILE_F + (32 + j) * BQ_TS + h * 32);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const f32x4 u = p0[i], w = p1[i];
-            a0[4 * i] = u.x; a0[4 * i + 1] = u.y; a0[4 * i + 2] = u.z; a0[4 * i + 3] = u.w;
-            a1[4 * i] = w.x; a1[4 * i + 1] = w.y; a1[4 * i + 2] = w.z; a1[4 * i + 3] = w.w;
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 u = p0[i], w = p1[i];
+                a0[4 * i] = u.x; a0[4 * i + 1] = u.y; a0[4 * i + 2] = u.z; a0[4 * i + 3] = u.w;
+                a1[4 * i] = w.x; a1[4 * i + 1] = w.y; a1[4 * i + 2] = w.z; a1[4 * i + 3] = w.w;
+            }
+        } else {
+            // lane (j, h), k-step s: 8 consecutive bf16 = dims 16s + 8h .. +7 of row j -> one ds_read_b128 at
+            // byte 32s + 16h of the row (hi) and 128 + 32s + 16h (lo); conflict-free at the 272-byte stride
+            const char* p0 = reinterpret_cast<const char*>(tile + (size_t)buf * BQ_TILE_F + j * BQ_TS) + 16 * h;
+            const char* p1 = reinterpret_cast<const char*>(tile + (size_t)buf * BQ_TILE_F + (32 + j) * BQ_TS) + 16 * h;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                a0h[s] = *reinterpret_cast<const bf16x8*>(p0 + 32 * s);
+                a0l[s] = *reinterpret_cast<const bf16x8*>(p0 + 128 + 32 * s);
+                a1h[s] = *reinterpret_cast<const bf16x8*>(p1 + 32 * s);
+                a1l[s] = *reinterpret_cast<const bf16x8*>(p1 + 128 + 32 * s);
+            }
         }
     };
     store_half(0, 0, load_half(st, 0));
@@ -682,11 +725,29 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
 #if LBH_BQ_ABLATE == 1  // timing-only build: no matrix work
 #pragma unroll
             for (int s = 0; s < 32; ++s) { acc0[s & 15] += a0[s] * b[s]; acc1[s & 15] += a1[s] * b[s]; }
+            if (BF16) asm volatile("" ::"v"(a0h[0]), "v"(a0l[0]), "v"(a1h[0]), "v"(a1l[0]), "v"(bh[0]), "v"(bl[0]));
 #else
+            if (!BF16) {
 #pragma unroll
-            for (int s = 0; s < 32; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b[s], acc0, 0, 0, 0);
+                for (int s = 0; s < 32; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b[s], acc0, 0, 0, 0);
 #pragma unroll
-            for (int s = 0; s < 32; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b[s], acc1, 0, 0, 0);
+                for (int s = 0; s < 32; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b[s], acc1, 0, 0, 0);
+            } else {
+                // x*q ~ hi*hi + hi*lo + lo*hi (the dropped lo*lo and the split residues are < 3 * 2^-18 |x q|):
+                // 12 MFMAs of 32 cycles per tile instead of 32 of 64; cross terms first, they are the small ones
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l[s], bh[s], acc0, 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h[s], bl[s], acc0, 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h[s], bh[s], acc0, 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l[s], bh[s], acc1, 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h[s], bl[s], acc1, 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h[s], bh[s], acc1, 0, 0, 0);
+            }
 #endif
 #if LBH_BQ_ABLATE == 2  // timing-only build: no epilogue
             asm volatile("" ::"v"(acc0), "v"(acc1));
@@ -719,7 +780,7 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
 
 // Per-query seed threshold from the sample pass: (k-th best fp32 score of the sample) - margin.  The
 // sample is a subset of the corpus, so this never exceeds the final cut (global k-th - margin).
-__global__ __launch_bounds__(SEL_THREADS) void seed_batched_kernel(int k, const uint64_t* __restrict__ cand3,
+__global__ __launch_bounds__(SEL_THREADS) void seed_batched_kernel(int k, float margin, const uint64_t* __restrict__ cand3,
                                                                     int32_t* __restrict__ qtotal,
                                                                     uint32_t* __restrict__ seed) {
     __shared__ int hist[256];
@@ -737,7 +798,7 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_batched_kernel(int k, const 
             return true;
         };
         const uint32_t kth = (uint32_t)block_radix_select(E, 4, k, val, hist, &sh_krem, &sh_bin);
-        thr = lbh_ord32(lbh_unord32(kth) - LBH_MARGIN);
+        thr = lbh_ord32(lbh_unord32(kth) - margin);
     }
     __syncthreads();
     if (threadIdx.x == 0) { seed[q] = thr; qtotal[q] = raw & BQ_OVER; }
@@ -745,7 +806,7 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_batched_kernel(int k, const 
 
 // K4 for a batch: one block per query.
 __global__ __launch_bounds__(SEL_THREADS) void select_batched_kernel(lbh_dev_index ix, const double* __restrict__ qmat,
-                                                                      int k, const uint64_t* __restrict__ cand3,
+                                                                      int k, float margin, const uint64_t* __restrict__ cand3,
                                                                       const int32_t* __restrict__ qtotal,
                                                                       const int32_t* __restrict__ flags,
                                                                       lbh_result* __restrict__ res_arr) {
@@ -761,7 +822,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_batched_kernel(lbh_dev_ind
     }
     int E = raw;
     if (E > BQ_PERQ) E = BQ_PERQ;
-    select_fast_body(ix, qs, k, cand3 + (size_t)q * BQ_PERQ, E, res);
+    select_fast_body(ix, qs, k, cand3 + (size_t)q * BQ_PERQ, E, res, margin);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1269,7 +1330,7 @@ hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace&
 }
 
 hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspace& ws, int nq, int k, int has_since,
-                                     int64_t since_ms, uint64_t tag_mask, int n_cu, hipStream_t s, hipEvent_t ev0,
+                                     int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, hipStream_t s, hipEvent_t ev0,
                                      hipEvent_t ev1) {
     static bool attr_set = false;
     hipError_t e;
@@ -1284,6 +1345,7 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspac
         }
         attr_set = true;
     }
+    const float margin = bf16 ? LBH_MARGIN_BF16X3 : LBH_MARGIN;
     e = hipMemsetAsync(ws.flags, 0, 16, s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws.bq_total, 0, BQ_MAXQ * 4, s);
@@ -1293,12 +1355,12 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspac
         const int64_t tiles = (r1 - r0 + 63) / 64;
         const dim3 g((unsigned)(tiles < n_cu ? tiles : n_cu));
 #define LBH_BSCAN_ARGS ix, ws.bq_qmat, nq, k, since_ms, tag_mask, r0, r1, seed, ws.bq_cand, ws.bq_total, ws.flags
-        if (true) {  // the flavour with the slow path inlined (no spills at 200 VGPRs; a call per candidate tile cost more)
+        if (bf16) {  // split-bf16 products on v_mfma_f32_32x32x16_bf16
             if (has_since && tag_mask) scan_batched_kernel<true, true, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
             else if (has_since) scan_batched_kernel<true, false, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
             else if (tag_mask) scan_batched_kernel<false, true, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
             else scan_batched_kernel<false, false, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
-        } else {
+        } else {     // exact fp32 products on v_mfma_f32_32x32x2_f32
             if (has_since && tag_mask) scan_batched_kernel<true, true, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
             else if (has_since) scan_batched_kernel<true, false, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
             else if (tag_mask) scan_batched_kernel<false, true, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
@@ -1332,13 +1394,13 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspac
         const int64_t ns = ((ix.n >> shifts[i]) / 64) * 64;
         if (ns < 16384) continue;
         launch(0, ns, seed);
-        seed_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(k, ws.bq_cand, ws.bq_total, ws.bq_seed);
+        seed_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(k, margin, ws.bq_cand, ws.bq_total, ws.bq_seed);
         seed = ws.bq_seed;
     }
     launch(0, ix.n, seed);
     if (ev1) (void)hipEventRecord(ev1, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    select_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(ix, ws.bq_qmat, k, ws.bq_cand, ws.bq_total, ws.flags, ws.bq_result_dev);
+    select_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(ix, ws.bq_qmat, k, margin, ws.bq_cand, ws.bq_total, ws.flags, ws.bq_result_dev);
     return hipGetLastError();
 }
