@@ -54,6 +54,9 @@ typedef struct lbh_stats {
     int32_t fallbacks;        /* out: times the fp32 path overflowed into the exact path */
     float scan_ms;            /* out: total HIP-event time of the scoring kernel launches */
     float total_ms;           /* out: HIP-event time of everything enqueued by the call (want_timing >= 2, else 0) */
+    float max_score_err;      /* out: largest |scan score - exact fp64 score| over the rows that were re-scored: a live
+                                 check of the scan's error bound (must stay below half the candidate margin) */
+    int32_t reserved;
 } lbh_stats;
 
 /* ---- context -------------------------------------------------------------- */

@@ -46,7 +46,8 @@ struct lbh_ctx {
     std::string arch;
     int scan_blocks_per_cu = 2;  // tuning knobs (env LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT), see DESIGN.md
     int scan_nt = 1;
-    int bq_bf16 = 1;     // batched scan: 1 = split-bf16 products (3 MFMAs at 16x the fp32 rate), 0 = exact fp32 MFMA
+    int bq_mode = 2;     // batched scan: 0 = exact fp32 MFMA, 1 = split-bf16 products (3 MFMAs at 16x the fp32 rate),
+                         // 2 = one fp16 product (a third of the matrix work, margin 2.2e-3)
     int spin_us = 5000;  // poll the completion ticket this long before blocking in hipStreamSynchronize (0 = always block)
     std::mutex mu;  // serialises use of the scratch below
     // small scratch for embed / cosine calls
@@ -194,6 +195,7 @@ struct SearchAcc {
     int64_t rows_scanned = 0, bytes_per_row = 0, candidates = 0;
     int scan_launches = 0, fallbacks = 0;
     float scan_ms = 0.f;
+    float max_err = 0.f;
 };
 
 // one device pass producing up to `page` (<= 64) results; q32/q64 must already be in the workspace
@@ -238,6 +240,7 @@ int run_page(lbh_index* ix, int page, int64_t since_ms, uint64_t tag_mask, bool 
         if (r->overflow)
             return fail(LBH_E_INTERNAL, "exact path: more than %d claims tie on score and on the first 8 key bytes", LBH_MCAP);
         acc->candidates += r->candidates;
+        if (fast) acc->max_err = std::max(acc->max_err, r->max_err);
         out->count = r->count;
         memcpy(out->rows, r->rows, sizeof(uint32_t) * r->count);
         memcpy(out->scores, r->scores, sizeof(double) * r->count);
@@ -290,6 +293,7 @@ int search_loaded(lbh_index* ix, int64_t k, int64_t since_ms, uint64_t tag_mask,
         stats->rows_scanned = acc.rows_scanned;
         stats->bytes_per_row = acc.bytes_per_row;
         stats->candidates = acc.candidates;
+        stats->max_score_err = acc.max_err;
         stats->scan_launches = acc.scan_launches;
         stats->fallbacks = acc.fallbacks;
         stats->scan_ms = acc.scan_ms;
@@ -362,7 +366,7 @@ int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx) {
     c->arch = prop.gcnArchName;
     if (const char* e1 = getenv("LBH_SCAN_BLOCKS_PER_CU")) c->scan_blocks_per_cu = std::max(1, std::min(8, atoi(e1)));
     if (const char* e2 = getenv("LBH_SCAN_NT")) c->scan_nt = atoi(e2) != 0;
-    if (const char* e4 = getenv("LBH_BQ_BF16")) c->bq_bf16 = atoi(e4) != 0;
+    if (const char* e4 = getenv("LBH_BQ_MODE")) c->bq_mode = std::max(0, std::min(2, atoi(e4)));
     if (const char* e3 = getenv("LBH_SPIN_US")) c->spin_us = std::max(0, std::min(1000000, atoi(e3)));
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -396,7 +400,7 @@ int lbh_set_option(lbh_ctx* c, const char* name, int64_t value) {
     std::lock_guard<std::mutex> lk(c->mu);
     if (!strcmp(name, "scan_blocks_per_cu")) c->scan_blocks_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "scan_nt")) c->scan_nt = value != 0;
-    else if (!strcmp(name, "bq_bf16")) c->bq_bf16 = value != 0;
+    else if (!strcmp(name, "bq_mode")) c->bq_mode = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else if (!strcmp(name, "spin_us")) c->spin_us = (int)std::max<int64_t>(0, std::min<int64_t>(1000000, value));
     else return fail(LBH_E_INVALID, "unknown option %s", name);
     return LBH_OK;
@@ -789,7 +793,7 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
         for (int64_t q0 = 0; q0 < nq; q0 += LBH_BQ_MAXQ) {
             const int nb = (int)std::min<int64_t>(LBH_BQ_MAXQ, nq - q0);
             HIP_TRY(hipMemcpyAsync(ix->ws.bq_qmat, q_f64 + q0 * 64, (size_t)nb * 512, hipMemcpyHostToDevice, s));
-            HIP_TRY(lbh_launch_search_batched(dv, ix->ws, nb, (int)keff, has_since, since_ms, tag_mask, c->n_cu, c->bq_bf16, s,
+            HIP_TRY(lbh_launch_search_batched(dv, ix->ws, nb, (int)keff, has_since, since_ms, tag_mask, c->n_cu, c->bq_mode, s,
                                               timing ? c->ev[0] : nullptr, timing ? c->ev[1] : nullptr));
             HIP_TRY(hipStreamSynchronize(s));
             total.scan_launches += 1;
@@ -808,6 +812,7 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
                 }
                 out_counts[q] = r->count;
                 total.candidates += r->candidates;
+                total.max_score_err = std::max(total.max_score_err, r->max_err);
                 done[(size_t)q] = 1;
             }
         }
@@ -837,6 +842,7 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
             total.fallbacks += st.fallbacks;
             total.scan_ms += st.scan_ms;
             total.total_ms += st.total_ms;
+            total.max_score_err = std::max(total.max_score_err, st.max_score_err);
         }
     }
     if (stats) {

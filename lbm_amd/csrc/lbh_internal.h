@@ -26,6 +26,8 @@
 // partial sums <= ~1 add at most 192 * 2^-23 = 2.3e-5 even if the matrix pipe truncated instead of rounding.
 // eps < 3.5e-5, margin = 1e-4 > 2 eps.  lbh_stats.max_score_err reports the largest error actually seen.
 #define LBH_MARGIN_BF16X3 1.0e-4f
+// Batched scan with one fp16 product per dimension: eps < 2^-10 + 1e-5 (see scan_batched_f16_kernel).
+#define LBH_MARGIN_F16 2.2e-3f
 
 // ---- order-preserving integer images of floats ------------------------------------------------
 __host__ __device__ inline uint32_t lbh_ord32(float f) {
@@ -73,6 +75,8 @@ struct lbh_result {
     int32_t overflow;         // fp32 path could not bound its candidate set -> caller re-runs exactly
     int32_t candidates;       // rows that were re-scored in fp64
     int32_t seq;              // completion ticket: written last, after a system-scope fence (see publish_result)
+    float max_err;            // largest |scan score - exact fp64 score| among the re-scored rows (0 on the exact path)
+    int32_t pad;
     uint32_t rows[LBH_MAX_PAGE];
     double scores[LBH_MAX_PAGE];
     uint64_t keys[LBH_MAX_PAGE][4];   // hash keys of the results (shard merge, paging cursor)

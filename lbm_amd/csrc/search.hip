@@ -335,11 +335,20 @@ __device__ uint64_t block_radix_select(int E, int nbytes, int64_t krem, F val, i
 // shared tail of both final kernels: rows xr[0..M) (+ ord64 scores xo when have_scores) -> exact
 // scores -> exact sort -> result block
 __device__ void rerank_and_emit(uint64_t* xo, uint32_t* xr, int M, int k, const lbh_dev_index& ix,
-                                const double* qs, lbh_result* __restrict__ res, bool have_scores) {
+                                const double* qs, lbh_result* __restrict__ res, bool have_scores,
+                                uint32_t scan_ord0 = 0, uint32_t scan_ord1 = 0) {
     const int tid = threadIdx.x;
     const int n2 = pow2_at_least(M, 2);
+    __shared__ uint32_t sh_err;  // largest |scan score - exact score| among the re-scored rows (float bits, >= 0)
+    if (tid == 0) sh_err = 0;
+    __syncthreads();
     if (!have_scores) {
-        for (int j = tid; j < M; j += SEL_THREADS) xo[j] = lbh_ord64(exact_dot(qs, ix.emb64 + (size_t)xr[j] * 64));
+        for (int j = tid; j < M; j += SEL_THREADS) {
+            const double exact = exact_dot(qs, ix.emb64 + (size_t)xr[j] * 64);
+            xo[j] = lbh_ord64(exact);
+            const float err = (float)__builtin_fabs((double)lbh_unord32(j == tid ? scan_ord0 : scan_ord1) - exact);
+            atomicMax(&sh_err, __builtin_bit_cast(uint32_t, err));
+        }
     }
     for (int j = M + tid; j < n2; j += SEL_THREADS) { xo[j] = 0; xr[j] = PAD_ROW; }
     __syncthreads();
@@ -352,7 +361,7 @@ __device__ void rerank_and_emit(uint64_t* xo, uint32_t* xr, int M, int k, const 
 #pragma unroll
         for (int w = 0; w < 4; ++w) res->keys[tid][w] = ix.keys[(size_t)r * 4 + w];
     }
-    if (tid == 0) { res->count = cnt; res->overflow = 0; res->candidates = M; }
+    if (tid == 0) { res->count = cnt; res->overflow = 0; res->candidates = M; res->max_err = __builtin_bit_cast(float, sh_err); }
 }
 
 // K4 body: global fp32 threshold over E flat candidates, candidate cut, exact fp64 re-rank.
@@ -406,16 +415,18 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
         return;
     }
     // rows out of sbuf into registers, then re-use sbuf as (ord64[MCAP], rows[MCAP])
-    uint32_t myrows[2];
+    uint32_t myrows[2], myord[2];
     myrows[0] = tid < M ? (uint32_t)sbuf[tid] : PAD_ROW;
     myrows[1] = tid + SEL_THREADS < M ? (uint32_t)sbuf[tid + SEL_THREADS] : PAD_ROW;
+    myord[0] = tid < M ? (uint32_t)(sbuf[tid] >> 32) : 0u;
+    myord[1] = tid + SEL_THREADS < M ? (uint32_t)(sbuf[tid + SEL_THREADS] >> 32) : 0u;
     __syncthreads();
     uint64_t* xo = sbuf;
     uint32_t* xr = reinterpret_cast<uint32_t*>(sbuf + LBH_MCAP);
     if (tid < M) xr[tid] = myrows[0];
     if (tid + SEL_THREADS < M) xr[tid + SEL_THREADS] = myrows[1];
     __syncthreads();
-    rerank_and_emit(xo, xr, M, k, ix, qs, res, false);
+    rerank_and_emit(xo, xr, M, k, ix, qs, res, false, myord[0], myord[1]);
 }
 
 // Completion ticket: the result block lives in device-mapped pinned host memory, so once every writer
@@ -532,6 +543,76 @@ __device__ __forceinline__ void bq_compact_impl(const bq_ctx& c, int q) {
 
 __device__ __noinline__ void bq_compact(const bq_ctx& c, int q) { bq_compact_impl(c, q); }
 
+// All of a wave's queries at once: lane L serves query wave*32 + (L & 31); the two lanes of a query
+// (L, L + 32) each scan every other entry of its buffer, keeping a sorted top-KB list of scores in
+// registers, then merge their lists -> k-th best -> new threshold; lane L < 32 re-packs the buffer in
+// place.  One call costs about what bq_compact_impl costs for TWO queries, whatever the number of
+// queries in `need` -- with cold thresholds (sample pass, first tiles) every query needs it at once.
+template <int KB>
+__device__ __forceinline__ void bq_compact_all_impl(const bq_ctx& c, uint64_t need) {
+    const int lane = c.lane, qi = lane & 31, half = lane >> 5;
+    const int q = c.wave * 32 + qi;
+    const bool mine = (need >> qi) & 1ull;
+    uint64_t* buf = c.qbuf + (size_t)q * BQ_CAP;
+    int cnt = 0;
+    if (mine) cnt = c.qcnt[q] < BQ_CAP ? c.qcnt[q] : BQ_CAP;
+    uint32_t top[KB];
+#pragma unroll
+    for (int m = 0; m < KB; ++m) top[m] = 0u;
+    for (int i = half; i < cnt; i += 2) {
+        uint32_t v = (uint32_t)(buf[i] >> 32);
+#pragma unroll
+        for (int m = 0; m < KB; ++m) {
+            const uint32_t hi = top[m] > v ? top[m] : v;
+            v = top[m] > v ? v : top[m];
+            top[m] = hi;
+        }
+    }
+    // merge with the partner lane's list (same query, other half of the entries)
+    uint32_t other[KB];
+#pragma unroll
+    for (int m = 0; m < KB; ++m) other[m] = __shfl_xor(top[m], 32);
+#pragma unroll
+    for (int e = 0; e < KB; ++e) {
+        uint32_t v = other[e];
+#pragma unroll
+        for (int m = 0; m < KB; ++m) {
+            const uint32_t hi = top[m] > v ? top[m] : v;
+            v = top[m] > v ? v : top[m];
+            top[m] = hi;
+        }
+    }
+    if (mine && half == 0) {
+        uint32_t t2 = c.qthr[q];
+        int newcnt = cnt;
+        if (cnt >= c.k) {
+            uint32_t kth = 0;
+#pragma unroll
+            for (int m = 0; m < KB; ++m) kth = (m == c.k - 1) ? top[m] : kth;
+            const uint32_t nt = lbh_ord32(lbh_unord32(kth) - c.margin);
+            if (nt > t2) t2 = nt;
+            newcnt = 0;
+            for (int i = 0; i < cnt; i += 4) {  // in-place: the write position never passes the read position
+                uint64_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = i + u < cnt ? buf[i + u] : 0ull;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i + u < cnt && (uint32_t)(v[u] >> 32) >= t2) buf[newcnt++] = v[u];
+            }
+        }
+        c.qcnt[q] = newcnt;
+        c.qthr[q] = t2;
+        if (newcnt > BQ_TRIG) atomicOr(&c.qtotal[q], BQ_OVER);  // too many near-ties for this path: that query only
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void bq_compact_all(const bq_ctx& c, uint64_t need) {
+    if (c.k <= 8) bq_compact_all_impl<8>(c, need);
+    else bq_compact_all_impl<LBH_BQ_KMAX>(c, need);
+}
+
 // slow path of the K3 epilogue: exact ord compare, mask, append, compaction.  Returns the lane's
 // (possibly raised) threshold.  Inlined into the scan loop: an out-of-line call spilled the caller's live
 // registers around every candidate tile, which dominated the cold sample pass.
@@ -552,13 +633,18 @@ __device__ __forceinline__ uint32_t bq_harvest_impl(const bq_ctx& c, const f32x1
         }
     }
     __builtin_amdgcn_wave_barrier();
-    uint64_t need = __ballot(c.lane < 32 && c.qactive && c.qcnt[c.myq] > BQ_TRIG);
+    const uint64_t need = __ballot(c.lane < 32 && c.qactive && c.qcnt[c.myq] > BQ_TRIG);
     if (need) {
-        while (need) {
-            const int qi = __ffsll((long long)need) - 1;
-            need &= need - 1;
-            if (INL) bq_compact_impl(c, c.wave * 32 + qi);
-            else bq_compact(c, c.wave * 32 + qi);
+        if (__popcll(need) > 2) {
+            bq_compact_all(c, need);
+        } else {
+            uint64_t rest = need;
+            while (rest) {
+                const int qi = __ffsll((long long)rest) - 1;
+                rest &= rest - 1;
+                if (INL) bq_compact_impl(c, c.wave * 32 + qi);
+                else bq_compact(c, c.wave * 32 + qi);
+            }
         }
         if (c.qactive) thr = c.qthr[c.myq];
     }
@@ -625,8 +711,8 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
         // would expose the HBM latency every super-tile; rows >= n are dropped by row_mask() instead
         int64_t r = row_begin + st * 64 + half * 32 + srow;
         r = r < n ? r : n - 1;
-#if LBH_BQ_ABLATE == 3  // timing-only build: no HBM traffic in the loop (every tile is the first one)
-        r = srow;
+#if LBH_BQ_ABLATE == 4  // timing-only build: loads stay inside a 1 MiB, L2-resident window
+        r &= 4095;
 #endif
         return __builtin_nontemporal_load(&E[r * 16 + sc4]);
     };
@@ -650,7 +736,6 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
     bc.qbuf = qbuf; bc.qcnt = qcnt; bc.qthr = qthr; bc.qtotal = qtotal;
     bc.k = k; bc.lane = lane; bc.wave = wave; bc.myq = myq; bc.h = h; bc.qactive = qactive;
     bc.margin = BF16 ? LBH_MARGIN_BF16X3 : LBH_MARGIN;
-    auto compact_query = [&](int q) { bq_compact(bc, q); };
 
     // rows of one 32-claim tile that pass the since / tag filters, as one word (lanes 0..31 vote)
     auto row_mask = [&](int64_t row0) -> uint32_t {
@@ -709,14 +794,23 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
     };
     store_half(0, 0, load_half(st, 0));
     store_half(0, 1, load_half(st, 1));
+    // global loads run TWO super-tiles ahead (one iteration is shorter than the loaded HBM latency once the
+    // MFMAs are the short bf16 ones): nx = tile it+1 (stored this iteration), ny = tile it+2
     f32x4 nx0 = load_half(st + G, 0), nx1 = load_half(st + G, 1);
+    f32x4 ny0 = load_half(st + 2 * G, 0), ny1 = load_half(st + 2 * G, 1);
     __syncthreads();
     if (wave_active) read_frags(0);
     for (int it = 0; st < n_super; st += G, ++it) {
+#if LBH_BQ_ABLATE == 6  // timing-only build: loaded data is consumed but not staged
+        asm volatile("" ::"v"(nx0), "v"(nx1));
+#else
         store_half((it + 1) & 1, 0, nx0);   // super-tile it+1 (prefetched during the previous iteration)
         store_half((it + 1) & 1, 1, nx1);
-        nx0 = load_half(st + 2 * G, 0);
-        nx1 = load_half(st + 2 * G, 1);
+#endif
+        nx0 = ny0;
+        nx1 = ny1;
+        ny0 = load_half(st + 3 * G, 0);
+        ny1 = load_half(st + 3 * G, 1);
         if (wave_active) {
             const int64_t row0 = row_begin + st * 64;
             const uint32_t m0 = row_mask(row0), m1 = row_mask(row0 + 32);
@@ -735,21 +829,32 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
             } else {
                 // x*q ~ hi*hi + hi*lo + lo*hi (the dropped lo*lo and the split residues are < 3 * 2^-18 |x q|):
                 // 12 MFMAs of 32 cycles per tile instead of 32 of 64; cross terms first, they are the small ones
+#if LBH_BQ_ABLATE == 8  // timing-only build: every fragment is read and waited for, no matrix work
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l[s], bh[s], acc0, 0, 0, 0);
+                for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(a0l[s]), "v"(a0h[s]), "v"(a1l[s]), "v"(a1h[s]), "v"(bh[s]), "v"(bl[s]));
+#else
+                // the two tiles' chains alternate, so consecutive MFMAs never depend on each other
+#if LBH_BQ_ABLATE != 7  // 7: timing-only build with a third of the matrix work (hi*hi only)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h[s], bl[s], acc0, 0, 0, 0);
+                for (int s = 0; s < 4; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l[s], bh[s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l[s], bh[s], acc1, 0, 0, 0);
+                }
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h[s], bh[s], acc0, 0, 0, 0);
+                for (int s = 0; s < 4; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h[s], bl[s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h[s], bl[s], acc1, 0, 0, 0);
+                }
+#endif
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l[s], bh[s], acc1, 0, 0, 0);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h[s], bl[s], acc1, 0, 0, 0);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h[s], bh[s], acc1, 0, 0, 0);
+                for (int s = 0; s < 4; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h[s], bh[s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h[s], bh[s], acc1, 0, 0, 0);
+                }
+#endif
             }
 #endif
-#if LBH_BQ_ABLATE == 2  // timing-only build: no epilogue
+#if LBH_BQ_ABLATE >= 2  // timing-only builds: no epilogue
             asm volatile("" ::"v"(acc0), "v"(acc1));
 #else
             if (any_hit(acc0)) harvest(acc0, row0, m0);
@@ -757,23 +862,182 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
 #endif
         }
         __syncthreads();
+#if LBH_BQ_ABLATE != 5  // 5: timing-only build without the per-tile fragment reads
         if (wave_active) read_frags((it + 1) & 1);
+#endif
     }
     // flush: final cut per query, then append to the query's flat candidate list in HBM
     if (wave_active) {
+        bq_compact_all(bc, __ballot(lane < 32 && qactive && qcnt[myq] > 0));
+        // one global atomic round trip for the wave's 32 queries (lane = query), then the copies
+        int mycnt = 0, mybase = 0;
+        if (lane < 32 && qactive) {
+            mycnt = qcnt[myq] < BQ_CAP ? qcnt[myq] : BQ_CAP;
+            if (mycnt) {
+                mybase = atomicAdd(&qtotal[myq], mycnt) & (BQ_OVER - 1);
+                if (mybase + mycnt > BQ_PERQ) {
+                    atomicOr(&qtotal[myq], BQ_OVER);
+                    mycnt = 0;
+                }
+            }
+        }
         for (int qi = 0; qi < 32 && wave * 32 + qi < nq; ++qi) {
             const int q = wave * 32 + qi;
-            if (qcnt[q] == 0) continue;
-            compact_query(q);
-            const int cnt = qcnt[q] < BQ_CAP ? qcnt[q] : BQ_CAP;
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&qtotal[q], cnt) & (BQ_OVER - 1);
-            base = __shfl(base, 0);
-            if (base + cnt > BQ_PERQ) {
-                if (lane == 0) atomicOr(&qtotal[q], BQ_OVER);
-            } else if (lane < cnt) {
-                cand3[(size_t)q * BQ_PERQ + base + lane] = qbuf[(size_t)q * BQ_CAP + lane];
+            const int cnt = __shfl(mycnt, qi), base = __shfl(mybase, qi);
+            if (lane < cnt) cand3[(size_t)q * BQ_PERQ + base + lane] = qbuf[(size_t)q * BQ_CAP + lane];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3, fp16 flavour: ONE v_mfma_f32_32x32x16_f16 product per k-step (4 MFMAs per 32x32 tile instead of 12).
+// Why: the split-bf16 kernel above is power-bound, not issue-bound.  tools/mfma_rate.hip measures 13.4 ns
+// per 32x32x16 MFMA on an idle chip, 16.7 ns with every CU issuing and 20 ns with random operand bits
+// (the clock drops under matrix load); three re-orderings of that kernel (phase-staggered waves, staging
+// slices between the MFMAs, alternating chains) all ran in 1.13-1.18 ms, and a timing-only build with a
+// third of the MFMAs took 0.52 ms.  Less matrix work is the only lever, and the exact re-rank makes it safe:
+// the scan only has to bound its error.  fp16 keeps 11 significant bits, so |fp16(x) fp16(q) - x q| <=
+// (2^-11 + 2^-11 + 2^-22) |x q|; summed over a pair of unit vectors (sum |x_i q_i| <= 1) that is < 9.8e-4,
+// plus 64 fp32 accumulations (< 1e-5) and fp16 denormal flushes of components below 6e-5 (< 64 * 6e-5 * 6e-5).
+// eps < 1e-3, margin LBH_MARGIN_F16 = 2.2e-3 > 2 eps.  On the bench corpus that admits < 1 extra candidate per
+// query and million claims.  Same LDS rows (272 B; the fp16 image uses the first 128), same candidate code.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <bool SINCE, bool TAGS>
+__global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_index ix, const double* __restrict__ qmat,
+                                                                       int nq, int k, int64_t since_ms, uint64_t tag_mask,
+                                                                       int64_t row_begin, int64_t row_end,
+                                                                       const uint32_t* __restrict__ seed,
+                                                                       uint64_t* __restrict__ cand3,
+                                                                       int32_t* __restrict__ qtotal,
+                                                                       int32_t* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* qbuf = reinterpret_cast<uint64_t*>(smem);
+    float* tile = reinterpret_cast<float*>(smem + (size_t)BQ_MAXQ * BQ_CAP * 8);
+    int* qcnt = reinterpret_cast<int*>(smem + (size_t)BQ_MAXQ * BQ_CAP * 8 + BQ_NBUF * BQ_TILE_F * 4);
+    uint32_t* qthr = reinterpret_cast<uint32_t*>(qcnt + BQ_MAXQ);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int myq = wave * 32 + j;
+    const bool qactive = myq < nq;
+    const bool wave_active = wave * 32 < nq;
+    const int64_t n = row_end < ix.n ? row_end : ix.n;
+    const f32x4* __restrict__ E = reinterpret_cast<const f32x4*>(ix.emb32);
+
+    if (tid < BQ_MAXQ) { qcnt[tid] = 0; qthr[tid] = (seed && tid < nq) ? seed[tid] : 0u; }
+    f16x8 bq[4];  // B operand: k-step s holds dims 16s + 8h .. +7 of this lane's query
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v0 = (float)qmat[(size_t)(qactive ? myq : 0) * 64 + 16 * s + 8 * h + e];
+            bq[s][e] = (_Float16)(qactive ? v0 : 0.f);
+        }
+    }
+    uint32_t thr = (seed && qactive) ? seed[myq] : 0u;
+    float thr_f = qactive ? (thr ? lbh_unord32(thr) : -__builtin_inff()) : __builtin_inff();
+
+    const int64_t n_super = n > row_begin ? (n - row_begin + 63) >> 6 : 0;
+    const int64_t G = gridDim.x;
+    int64_t st = blockIdx.x;
+    const int srow = tid >> 4, sc4 = tid & 15;
+    auto load_half = [&](int64_t sti, int half) -> f32x4 {  // always issued, row clamped (see the first kernel)
+        int64_t r = row_begin + sti * 64 + half * 32 + srow;
+        r = r < n ? r : n - 1;
+        return __builtin_nontemporal_load(&E[r * 16 + sc4]);
+    };
+    auto store_half = [&](int buf, int half, f32x4 v) {  // round-to-nearest-even conversion (the bound above needs it)
+        char* d = reinterpret_cast<char*>(tile + (size_t)buf * BQ_TILE_F + (half * 32 + srow) * BQ_TS) + 8 * sc4;
+        *reinterpret_cast<f16x4*>(d) = __builtin_convertvector(v, f16x4);
+    };
+    bq_ctx bc;
+    bc.qbuf = qbuf; bc.qcnt = qcnt; bc.qthr = qthr; bc.qtotal = qtotal;
+    bc.k = k; bc.lane = lane; bc.wave = wave; bc.myq = myq; bc.h = h; bc.qactive = qactive;
+    bc.margin = LBH_MARGIN_F16;
+    auto row_mask = [&](int64_t row0) -> uint32_t {
+        bool rv = false;
+        if (lane < 32) {
+            const int64_t r = row0 + lane;
+            rv = r < n;
+            if (SINCE) rv = rv && ix.created[rv ? r : 0] >= since_ms;
+            if (TAGS) rv = rv && (ix.tags[r < n ? r : 0] & tag_mask) != 0;
+        }
+        return (uint32_t)__ballot(rv);
+    };
+    auto any_hit = [&](const f32x16& acc) -> bool {
+        bool hit = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hit |= acc[r] >= thr_f;
+        return __any(hit);
+    };
+    auto harvest = [&](const f32x16& acc, int64_t row0, uint32_t rowmask) {
+        thr = bq_harvest_impl<true>(bc, acc, row0, rowmask, thr);
+        if (qactive) thr_f = thr ? lbh_unord32(thr) : -__builtin_inff();
+    };
+
+    f16x8 a0[4], a1[4];
+    auto read_frags = [&](int buf) {  // lane (j, h), k-step s: one ds_read_b128 at byte 32s + 16h of row j (conflict-free)
+        const char* p0 = reinterpret_cast<const char*>(tile + (size_t)buf * BQ_TILE_F + j * BQ_TS) + 16 * h;
+        const char* p1 = reinterpret_cast<const char*>(tile + (size_t)buf * BQ_TILE_F + (32 + j) * BQ_TS) + 16 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a0[s] = *reinterpret_cast<const f16x8*>(p0 + 32 * s);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a1[s] = *reinterpret_cast<const f16x8*>(p1 + 32 * s);
+    };
+
+    store_half(0, 0, load_half(st, 0));
+    store_half(0, 1, load_half(st, 1));
+    f32x4 nx0 = load_half(st + G, 0), nx1 = load_half(st + G, 1);          // super-tile it+1: staged this iteration
+    f32x4 ny0 = load_half(st + 2 * G, 0), ny1 = load_half(st + 2 * G, 1);  // super-tile it+2
+    __syncthreads();
+    if (wave_active) read_frags(0);
+    for (int it = 0; st < n_super; st += G, ++it) {
+        const int nb = (it + 1) & 1;
+        store_half(nb, 0, nx0);
+        store_half(nb, 1, nx1);
+        nx0 = ny0; nx1 = ny1;
+        ny0 = load_half(st + 3 * G, 0);
+        ny1 = load_half(st + 3 * G, 1);
+        if (wave_active) {
+            const int64_t row0 = row_begin + st * 64;
+            const uint32_t m0 = row_mask(row0), m1 = row_mask(row0 + 32);
+            f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 acc1 = acc0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[s], bq[s], acc0, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[s], bq[s], acc1, 0, 0, 0);
+#if LBH_BQ_ABLATE >= 2  // timing-only builds: no epilogue
+            asm volatile("" ::"v"(acc0), "v"(acc1), "s"(m0), "s"(m1));
+#else
+            if (any_hit(acc0)) harvest(acc0, row0, m0);
+            if (any_hit(acc1)) harvest(acc1, row0 + 32, m1);
+#endif
+        }
+        __syncthreads();
+        if (wave_active) read_frags(nb);
+    }
+    // flush: final cut per query, then append to the query's flat candidate list in HBM
+    if (wave_active) {
+        bq_compact_all(bc, __ballot(lane < 32 && qactive && qcnt[myq] > 0));
+        int mycnt = 0, mybase = 0;
+        if (lane < 32 && qactive) {
+            mycnt = qcnt[myq] < BQ_CAP ? qcnt[myq] : BQ_CAP;
+            if (mycnt) {
+                mybase = atomicAdd(&qtotal[myq], mycnt) & (BQ_OVER - 1);
+                if (mybase + mycnt > BQ_PERQ) {
+                    atomicOr(&qtotal[myq], BQ_OVER);
+                    mycnt = 0;
+                }
             }
+        }
+        for (int qi = 0; qi < 32 && wave * 32 + qi < nq; ++qi) {
+            const int q = wave * 32 + qi;
+            const int cnt = __shfl(mycnt, qi), base = __shfl(mybase, qi);
+            if (lane < cnt) cand3[(size_t)q * BQ_PERQ + base + lane] = qbuf[(size_t)q * BQ_CAP + lane];
         }
     }
 }
@@ -1338,14 +1602,16 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspac
         const void* fns[] = {(const void*)scan_batched_kernel<true, true, false>, (const void*)scan_batched_kernel<true, false, false>,
                              (const void*)scan_batched_kernel<false, true, false>, (const void*)scan_batched_kernel<false, false, false>,
                              (const void*)scan_batched_kernel<true, true, true>, (const void*)scan_batched_kernel<true, false, true>,
-                             (const void*)scan_batched_kernel<false, true, true>, (const void*)scan_batched_kernel<false, false, true>};
+                             (const void*)scan_batched_kernel<false, true, true>, (const void*)scan_batched_kernel<false, false, true>,
+                             (const void*)scan_batched_f16_kernel<true, true>, (const void*)scan_batched_f16_kernel<true, false>,
+                             (const void*)scan_batched_f16_kernel<false, true>, (const void*)scan_batched_f16_kernel<false, false>};
         for (const void* f : fns) {
             e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BQ_LDS);
             if (e != hipSuccess) return e;
         }
         attr_set = true;
     }
-    const float margin = bf16 ? LBH_MARGIN_BF16X3 : LBH_MARGIN;
+    const float margin = bf16 == 2 ? LBH_MARGIN_F16 : bf16 ? LBH_MARGIN_BF16X3 : LBH_MARGIN;
     e = hipMemsetAsync(ws.flags, 0, 16, s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws.bq_total, 0, BQ_MAXQ * 4, s);
@@ -1355,7 +1621,12 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspac
         const int64_t tiles = (r1 - r0 + 63) / 64;
         const dim3 g((unsigned)(tiles < n_cu ? tiles : n_cu));
 #define LBH_BSCAN_ARGS ix, ws.bq_qmat, nq, k, since_ms, tag_mask, r0, r1, seed, ws.bq_cand, ws.bq_total, ws.flags
-        if (bf16) {  // split-bf16 products on v_mfma_f32_32x32x16_bf16
+        if (bf16 == 2) {  // one fp16 product per k-step
+            if (has_since && tag_mask) scan_batched_f16_kernel<true, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+            else if (has_since) scan_batched_f16_kernel<true, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+            else if (tag_mask) scan_batched_f16_kernel<false, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+            else scan_batched_f16_kernel<false, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+        } else if (bf16) {  // split-bf16 products on v_mfma_f32_32x32x16_bf16
             if (has_since && tag_mask) scan_batched_kernel<true, true, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
             else if (has_since) scan_batched_kernel<true, false, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
             else if (tag_mask) scan_batched_kernel<false, true, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);

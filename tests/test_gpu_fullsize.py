@@ -68,8 +68,17 @@ def test_fast_vs_exact_vs_batched_10m(corpus):
     hip, ix, q = corpus["hip"], corpus["ix"], corpus["q"]
     assert ix.size() == N_FULL
     st = hip.Stats()
-    bi, bs, bc = ix.search(q, 8, hip.SINCE_NONE, 0, st)  # K3
-    assert st.path == 2 and st.fallbacks == 0
+    # K3 in its three scan precisions (fp32 MFMA, split bf16, fp16): identical answers, measured scan error inside
+    # the bound the candidate margin assumes
+    batched = {}
+    for mode, margin in ((0, 1.0e-5), (1, 1.0e-4), (2, 2.2e-3)):
+        hip.set_option("bq_mode", mode)
+        batched[mode] = ix.search(q, 8, hip.SINCE_NONE, 0, st)
+        assert st.path == 2 and 0.0 < st.max_score_err < margin / 2, (mode, st.max_score_err)
+        assert st.fallbacks == 0 or mode == 2, (mode, st.fallbacks)  # the wide fp16 margin may hand a query over
+    for mode in (0, 1):
+        assert batched[mode][0].tolist() == batched[2][0].tolist() and batched[mode][1].tobytes() == batched[2][1].tobytes()
+    bi, bs, bc = batched[2]
     for j in range(q.shape[0]):
         i8, s8, _ = ix.search_shard(q[j], 8, hip.SINCE_NONE, 0, st)
         assert st.path == 0 and st.fallbacks == 0

@@ -324,8 +324,22 @@ def test_tags_extension_matches_oracle(hip):
             og.compile(q, top_k=16, tags=["t00"], since_ms=int(ch.created_ms[2000]))
 
 
-def test_batched_queries_mfma_path_vs_oracle(hip):
-    """K3: many queries in one pass on the matrix cores; every query must equal the oracle bit-for-bit."""
+# K3 scan arithmetic: (option value, candidate margin).  Whatever the scan's precision, results are exact:
+# the margin is twice the scan's error bound and every candidate is re-scored in fp64.
+BQ_MODES = {"fp32_mfma": (0, 1.0e-5), "bf16_split3": (1, 1.0e-4), "fp16": (2, 2.2e-3)}
+
+
+@pytest.fixture(params=list(BQ_MODES))
+def bq_mode(request, hip):
+    mode, margin = BQ_MODES[request.param]
+    hip.set_option("bq_mode", mode)
+    yield margin
+    hip.set_option("bq_mode", 2)
+
+
+def test_batched_queries_mfma_path_vs_oracle(hip, bq_mode):
+    """K3: many queries in one pass on the matrix cores; every query must equal the oracle bit-for-bit,
+    and the scan's measured error must stay inside the bound its candidate margin assumes."""
     from lbm_amd import synth
     ch = _arrays_case(150_000, 123)
     ix = hip.Index()
@@ -342,6 +356,7 @@ def test_batched_queries_mfma_path_vs_oracle(hip):
     for k, since, tmask in ((8, None, 0), (16, p50, 0), (1, None, 0b110), (8, p50, 1 << 7 | 1)):
         gi, gs, cnt = ix.search(qv, k, hip.SINCE_NONE if since is None else since, tmask, st)
         assert st.path == 2 and st.scan_launches >= 1
+        assert 0.0 <= st.max_score_err < bq_mode / 2, st.max_score_err
         for j in range(len(texts)):
             want_idx, want_sc = orc.compile_arrays(emb, ch.created_ms, retr, None, qv[j], k, since, ch.tagmask, tmask,
                                                    packed_keys=packed)
@@ -354,6 +369,7 @@ def test_batched_queries_mfma_path_vs_oracle(hip):
     qm = hip.embed_batch(many)
     gi, gs, cnt = ix.search(qm, 8, hip.SINCE_NONE, 0, st)
     assert st.path == 2 and st.scan_launches == 2 and st.fallbacks == 0
+    assert 0.0 < st.max_score_err < bq_mode / 2
     for j in (0, 1, 128, 255, 256, 257, 299):
         want_idx, want_sc = orc.compile_arrays(emb, ch.created_ms, retr, None, qm[j], 8, None, packed_keys=packed)
         assert gi[j, : int(cnt[j])].tolist() == want_idx.tolist() and gs[j, : int(cnt[j])].tobytes() == want_sc.tobytes()
