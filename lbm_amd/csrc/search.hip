@@ -1643,13 +1643,13 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspac
     // Sample passes seed every query's threshold before the full pass: with cold thresholds nearly every
     // tile holds candidates and the (VALU + LDS) harvest path, not the matrix pipe, sets the pace.  Each
     // pass scans the first n >> shift rows starting from the previous pass's seeds (a subset's k-th best
-    // never exceeds the corpus's, so seeds are always valid lower bounds).  Default: n/512, then n/32
-    // (measured at 10 M x 256: 0.21 + 0.16 ms of sample passes, 2.78 ms full pass; see profiles/).
-    static int shifts[4] = {9, 5, 0, 0};
+    // never exceeds the corpus's, so seeds are always valid lower bounds).  Default: n/256, then n/16
+    // (measured at 10 M x 256 with the fp16 scan: "8,4" 0.82 ms, "9,5" 0.86, "6" 0.98, "8,4,2" 0.95).
+    static int shifts[4] = {8, 4, 0, 0};
     static int n_shifts = -1;
     if (n_shifts < 0) {
         n_shifts = 2;
-        if (const char* ev = getenv("LBH_BQ_SAMPLE_SHIFTS")) {  // e.g. "9,5" (default), "6", "" = none
+        if (const char* ev = getenv("LBH_BQ_SAMPLE_SHIFTS")) {  // e.g. "8,4" (default), "6", "" = none
             n_shifts = 0;
             for (const char* p = ev; *p && n_shifts < 4;) {
                 char* end;

@@ -106,26 +106,33 @@ def main():
     out["config5_filtered_queries"] = {
         "since_p50_k8": time_single(ix, qv, 8, p50, 0), "since_p90_k8": time_single(ix, qv, 8, p90, 0),
         "tags3_k8": time_single(ix, qv, 8, _hip.SINCE_NONE, 0b111), "since_p50_tags3_k8": time_single(ix, qv, 8, p50, 0b111)}
-    # config 3: batched
+    # config 3: batched, in each scan precision (bq_mode 2 = fp16 is the default)
     st = _hip.Stats()
     st.want_timing = 1
-    res = {}
-    for nq in (256, 64, 16):
-        ix.search(qv[:nq], 8, _hip.SINCE_NONE, 0, st)
-        wall, scan = [], []
-        for r in range(8):
-            t0 = time.perf_counter()
-            ix.search(qv[:nq], 8, _hip.SINCE_NONE, 0, st)
-            wall.append(time.perf_counter() - t0)
-            scan.append(st.scan_ms * 1e-3)
-        w, s = float(np.median(wall)), float(np.median(scan))
-        fl = 2.0 * 64 * nq * n
-        res[f"q{nq}"] = {"claims": n, "queries": nq, "top_k": 8, "wall_ms": w * 1e3, "scan_ms": s * 1e3, "pairs_per_s": n * nq / w,
-                         "scan_TFLOPs": fl / s / 1e12, "frac_of_fp32_mfma_peak_157.3TF": fl / s / 157.3e12, "path": st.path,
-                         "fallbacks": st.fallbacks, "vs_looping_single_query_path": None}
     single = out["config4_shard_single_query"]["k8"]["p50_ms"]
-    for v in res.values():
-        v["vs_looping_single_query_path"] = single * v["queries"] / v["wall_ms"]
+    res = {}
+    for mode, name, mfma_per_pair_dim in ((2, "fp16", 1), (1, "bf16_split3", 3), (0, "fp32_mfma", 1)):
+        _hip.set_option("bq_mode", mode)
+        for nq in ((256, 64, 16) if mode == 2 else (256,)):
+            ix.search(qv[:nq], 8, _hip.SINCE_NONE, 0, st)
+            wall, scan, err = [], [], 0.0
+            for r in range(8):
+                t0 = time.perf_counter()
+                ix.search(qv[:nq], 8, _hip.SINCE_NONE, 0, st)
+                wall.append(time.perf_counter() - t0)
+                scan.append(st.scan_ms * 1e-3)
+                err = max(err, st.max_score_err)
+            w, s = float(np.median(wall)), float(np.median(scan))
+            useful = 2.0 * 64 * nq * n            # flops of the scores themselves
+            issued = useful * mfma_per_pair_dim   # flops the matrix pipe executes (3 products in the split-bf16 mode)
+            peak = 157.3e12 if mode == 0 else 2500e12
+            res[f"{name}_q{nq}"] = {"claims": n, "queries": nq, "top_k": 8, "wall_ms": w * 1e3, "scan_ms": s * 1e3,
+                                    "pairs_per_s": n * nq / w, "useful_TFLOPs": useful / s / 1e12,
+                                    "mfma_TFLOPs_issued": issued / s / 1e12, "frac_of_dense_mfma_peak": issued / s / peak,
+                                    "mfma_peak_TFLOPs": peak / 1e12, "scan_GBps_of_claim_bytes": n * 256 / s / 1e9,
+                                    "max_score_err": err, "path": st.path, "fallbacks": st.fallbacks,
+                                    "vs_looping_single_query_path": single * nq / (w * 1e3)}
+    _hip.set_option("bq_mode", 2)
     out["config3_batched_mfma"] = res
     print(json.dumps(out, indent=1))
 
