@@ -461,13 +461,8 @@ int lbh_cosine(lbh_ctx* c, const double* a, int64_t na, const double* b, int64_t
     return LBH_OK;
 }
 
-int lbh_index_create(lbh_ctx* c, lbh_index** out_idx) {
-    if (!c || !out_idx) return fail(LBH_E_INVALID, "bad argument");
-    *out_idx = nullptr;
-    HIP_TRY(hipSetDevice(c->device));
-    lbh_index* ix = new (std::nothrow) lbh_index();
-    if (!ix) return fail(LBH_E_NOMEM, "out of host memory");
-    ix->ctx = c;
+namespace {
+int index_alloc_workspace(lbh_index* ix) {
     lbh_workspace& w = ix->ws;
     HIP_TRY(hipMalloc((void**)&w.q64, 512));
     HIP_TRY(hipMalloc((void**)&w.cand, (size_t)LBH_MAX_BLOCKS * LBH_LIST_CAP * 8));
@@ -478,6 +473,24 @@ int lbh_index_create(lbh_ctx* c, lbh_index** out_idx) {
     HIP_TRY(hipHostGetDevicePointer((void**)&w.result_dev, w.result_host, 0));
     memset(w.result_host, 0, sizeof(lbh_result));
     HIP_TRY(hipMemset(w.flags, 0, 256));
+    return LBH_OK;
+}
+}  // namespace
+
+int lbh_index_create(lbh_ctx* c, lbh_index** out_idx) {
+    if (!c || !out_idx) return fail(LBH_E_INVALID, "bad argument");
+    *out_idx = nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    lbh_index* ix = new (std::nothrow) lbh_index();
+    if (!ix) return fail(LBH_E_NOMEM, "out of host memory");
+    ix->ctx = c;
+    const int rc = index_alloc_workspace(ix);
+    if (rc) {
+        const std::string why = g_err;  // lbh_index_destroy must not hide the reason
+        lbh_index_destroy(ix);
+        g_err = why;
+        return rc;
+    }
     *out_idx = ix;
     return LBH_OK;
 }

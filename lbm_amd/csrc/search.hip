@@ -18,6 +18,7 @@
 // This file is compiled with -ffp-contract=off: fp64 arithmetic must round like CPython floats.
 // FMAs in the fp32 scan are written explicitly (fmaf).
 #include <cstdlib>
+#include <mutex>
 
 #include "lbh_internal.h"
 
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
 // entries for which val(e, &v) is true.  All threads of the block call it; result is block-uniform.
 // ------------------------------------------------------------------------------------------------
 constexpr int SEL_THREADS = 1024;
+constexpr int LBH_SORT_ALL = 1024;  // select_fast_body: candidate lists up to this size are sorted whole
 
 template <class F>
 __device__ uint64_t block_radix_select(int E, int nbytes, int64_t krem, F val, int* hist, int64_t* sh_krem,
@@ -377,7 +379,7 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
     __syncthreads();
     int M = 0;
     uint32_t thr = 0;
-    if (E <= 2 * LBH_MCAP) {
+    if (E <= LBH_SORT_ALL) {  // few entries: sort them all; more: radix-select the k-th score first (a 4096-entry sort took 20+ us)
         for (int e = tid; e < E; e += SEL_THREADS) sbuf[e] = cand[e];
         const int n2 = pow2_at_least(E, 2);
         for (int i = E + tid; i < n2; i += SEL_THREADS) sbuf[i] = 0;
@@ -1596,9 +1598,12 @@ hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace&
 hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspace& ws, int nq, int k, int has_since,
                                      int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, hipStream_t s, hipEvent_t ev0,
                                      hipEvent_t ev1) {
-    static bool attr_set = false;
-    hipError_t e;
-    if (!attr_set) {
+    // one-time set-up (thread-safe: searches on different indexes may arrive concurrently)
+    static std::once_flag once;
+    static hipError_t once_err = hipSuccess;
+    static int shifts[4] = {8, 4, 0, 0};
+    static int n_shifts = 2;
+    std::call_once(once, [] {
         const void* fns[] = {(const void*)scan_batched_kernel<true, true, false>, (const void*)scan_batched_kernel<true, false, false>,
                              (const void*)scan_batched_kernel<false, true, false>, (const void*)scan_batched_kernel<false, false, false>,
                              (const void*)scan_batched_kernel<true, true, true>, (const void*)scan_batched_kernel<true, false, true>,
@@ -1606,11 +1611,22 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspac
                              (const void*)scan_batched_f16_kernel<true, true>, (const void*)scan_batched_f16_kernel<true, false>,
                              (const void*)scan_batched_f16_kernel<false, true>, (const void*)scan_batched_f16_kernel<false, false>};
         for (const void* f : fns) {
-            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BQ_LDS);
-            if (e != hipSuccess) return e;
+            const hipError_t e1 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BQ_LDS);
+            if (e1 != hipSuccess) once_err = e1;
         }
-        attr_set = true;
-    }
+        if (const char* ev = getenv("LBH_BQ_SAMPLE_SHIFTS")) {  // e.g. "8,4" (default), "6", "" = none
+            n_shifts = 0;
+            for (const char* p = ev; *p && n_shifts < 4;) {
+                char* end;
+                const long v = strtol(p, &end, 10);
+                if (end == p) break;
+                if (v > 0 && v < 32) shifts[n_shifts++] = (int)v;
+                p = (*end == ',') ? end + 1 : end;
+            }
+        }
+    });
+    if (once_err != hipSuccess) return once_err;
+    hipError_t e;
     const float margin = bf16 == 2 ? LBH_MARGIN_F16 : bf16 ? LBH_MARGIN_BF16X3 : LBH_MARGIN;
     e = hipMemsetAsync(ws.flags, 0, 16, s);
     if (e != hipSuccess) return e;
@@ -1645,21 +1661,6 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspac
     // pass scans the first n >> shift rows starting from the previous pass's seeds (a subset's k-th best
     // never exceeds the corpus's, so seeds are always valid lower bounds).  Default: n/256, then n/16
     // (measured at 10 M x 256 with the fp16 scan: "8,4" 0.82 ms, "9,5" 0.86, "6" 0.98, "8,4,2" 0.95).
-    static int shifts[4] = {8, 4, 0, 0};
-    static int n_shifts = -1;
-    if (n_shifts < 0) {
-        n_shifts = 2;
-        if (const char* ev = getenv("LBH_BQ_SAMPLE_SHIFTS")) {  // e.g. "8,4" (default), "6", "" = none
-            n_shifts = 0;
-            for (const char* p = ev; *p && n_shifts < 4;) {
-                char* end;
-                const long v = strtol(p, &end, 10);
-                if (end == p) break;
-                if (v > 0 && v < 32) shifts[n_shifts++] = (int)v;
-                p = (*end == ',') ? end + 1 : end;
-            }
-        }
-    }
     const uint32_t* seed = nullptr;
     for (int i = 0; i < n_shifts; ++i) {
         const int64_t ns = ((ix.n >> shifts[i]) / 64) * 64;
