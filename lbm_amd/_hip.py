@@ -236,6 +236,8 @@ class Index:
         h = _vp()
         _check(self._L.lbh_index_create(context(), ctypes.byref(h)))
         self._h = h
+        self._shard_bufs = {}
+        self._shard_lock = threading.Lock()  # the cached output buffers of search_shard are per index, not per thread
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -352,15 +354,27 @@ class Index:
 
     def search_shard(self, q: np.ndarray, k: int, since_ms: int = SINCE_NONE, tag_mask: int = 0,
                      stats: Optional[Stats] = None):
-        q = np.ascontiguousarray(q, dtype=np.float64).reshape(DIM)
+        """One query, local top-k with hash keys: (ids, scores, keys[n, 32]).  The latency path of the bench:
+        output buffers and their ctypes pointers are kept per k (building them costs more than the call)."""
+        if not (isinstance(q, np.ndarray) and q.dtype == np.float64 and q.shape == (DIM,) and q.flags.c_contiguous):
+            q = np.ascontiguousarray(q, dtype=np.float64).reshape(DIM)
         k = max(0, int(k))
-        kk = min(k, max(self.size(), 1))
-        ids = np.zeros(max(kk, 1), dtype=np.uint64)
-        sc = np.zeros(max(kk, 1), dtype=np.float64)
-        keys = np.zeros((max(kk, 1), KEY_BYTES), dtype=np.uint8)
-        cnt = _i64(0)
-        _check(self._L.lbh_index_search_shard(self._h, _ptr(q), kk, int(since_ms), int(tag_mask), _ptr(ids), _ptr(sc),
-                                              _ptr(keys), ctypes.byref(cnt),
-                                              ctypes.byref(stats) if stats is not None else None))
-        n = cnt.value
-        return ids[:n], sc[:n], keys[:n]
+        if k > 4096:  # never allocate for more results than there are claims
+            k = min(k, self.size())
+        with self._shard_lock:
+            buf = self._shard_bufs.get(k)
+            if buf is None:
+                if len(self._shard_bufs) > 64:
+                    self._shard_bufs.clear()
+                kk = max(k, 1)
+                ids = np.zeros(kk, dtype=np.uint64)
+                sc = np.zeros(kk, dtype=np.float64)
+                keys = np.zeros((kk, KEY_BYTES), dtype=np.uint8)
+                cnt = _i64(0)
+                buf = self._shard_bufs[k] = (ids, sc, keys, cnt, _ptr(ids), _ptr(sc), _ptr(keys), ctypes.byref(cnt))
+            ids, sc, keys, cnt, p_ids, p_sc, p_keys, p_cnt = buf
+            # the library clamps k to the number of live claims itself
+            _check(self._L.lbh_index_search_shard(self._h, q.ctypes.data, k, int(since_ms), int(tag_mask), p_ids, p_sc,
+                                                  p_keys, p_cnt, ctypes.byref(stats) if stats is not None else None))
+            n = cnt.value
+            return ids[:n].copy(), sc[:n].copy(), keys[:n].copy()
