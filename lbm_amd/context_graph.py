@@ -27,8 +27,10 @@ How the mirror works
 """
 from __future__ import annotations
 
+import functools
 import operator
 import re
+import threading
 import time
 from dataclasses import dataclass
 from typing import Any, Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
@@ -36,6 +38,26 @@ from typing import Any, Dict, Iterable, Iterator, List, Optional, Sequence, Tupl
 import numpy as np
 
 from . import _hip
+
+def _locked(fn):
+    """Run a ContextGraph method under the graph's re-entrant lock.  The reference's compile_context takes no
+    lock while writers hold BatteryNode._lock (lb/node.py:718 vs :465), so queries and publishes do overlap;
+    here both touch the device mirror's bookkeeping, which must not be seen half-updated."""
+    @functools.wraps(fn)
+    def wrapper(self, *a, **kw):
+        with self._lock:
+            return fn(self, *a, **kw)
+    return wrapper
+
+
+def _locked_g(fn):
+    """Same, for the helper objects that hold their graph in ``_g`` (claims dict, cache view)."""
+    @functools.wraps(fn)
+    def wrapper(self, *a, **kw):
+        with self._g._lock:
+            return fn(self, *a, **kw)
+    return wrapper
+
 
 _HEX64 = re.compile(r"[0-9a-f]{64}\Z")
 _HEXRUN = re.compile(r"[0-9a-f]*\Z")
@@ -100,6 +122,7 @@ class _ClaimDict(dict):
         self._g._seq_of.pop(k, None)  # a re-inserted key goes to the END of the dict order
         self._g._touch(k)
 
+    @_locked_g
     def __setitem__(self, k, v) -> None:
         if k not in self:  # assigning to an existing key keeps its position in the dict order
             g = self._g
@@ -109,10 +132,12 @@ class _ClaimDict(dict):
         super().__setitem__(k, v)
         self._adopt(k, v)
 
+    @_locked_g
     def __delitem__(self, k) -> None:
         super().__delitem__(k)
         self._forget(k)
 
+    @_locked_g
     def pop(self, k, *default):
         had = k in self
         r = super().pop(k, *default)
@@ -120,25 +145,30 @@ class _ClaimDict(dict):
             self._forget(k)
         return r
 
+    @_locked_g
     def popitem(self):
         k, v = super().popitem()
         self._forget(k)
         return k, v
 
+    @_locked_g
     def clear(self) -> None:
         for k in list(self.keys()):
             self._forget(k)
         super().clear()
 
+    @_locked_g
     def setdefault(self, k, default=None):
         if k not in self:
             self[k] = default
         return self[k]
 
+    @_locked_g
     def update(self, *a, **kw) -> None:
         for k, v in dict(*a, **kw).items():
             self[k] = v
 
+    @_locked_g
     def __ior__(self, other):
         self.update(other)
         return self
@@ -150,11 +180,13 @@ class _EmbeddingCacheView:
     def __init__(self, graph: "ContextGraph") -> None:
         self._g = graph
 
+    @_locked_g
     def __contains__(self, h) -> bool:
         g = self._g
         g._sync()
         return h in g._id_of or h in g._parked
 
+    @_locked_g
     def __getitem__(self, h) -> List[float]:
         g = self._g
         g._sync()
@@ -164,12 +196,14 @@ class _EmbeddingCacheView:
             return g._parked[h].tolist()
         raise KeyError(h)
 
+    @_locked_g
     def get(self, h, default=None):
         try:
             return self[h]
         except KeyError:
             return default
 
+    @_locked_g
     def __setitem__(self, h, vec) -> None:
         g = self._g
         g._sync()
@@ -180,6 +214,7 @@ class _EmbeddingCacheView:
         g._parked[h] = v
         g._touch(h)
 
+    @_locked_g
     def pop(self, h, *default):
         g = self._g
         g._sync()
@@ -193,23 +228,29 @@ class _EmbeddingCacheView:
             return default[0]
         raise KeyError(h)
 
+    @_locked_g
     def __delitem__(self, h) -> None:
         self.pop(h)
 
+    @_locked_g
     def keys(self) -> List[str]:
         g = self._g
         g._sync()
         return list(g._id_of.keys()) + [h for h in g._parked if h not in g._id_of]
 
+    @_locked_g
     def __iter__(self) -> Iterator[str]:
         return iter(self.keys())
 
+    @_locked_g
     def __len__(self) -> int:
         return len(self.keys())
 
+    @_locked_g
     def items(self):
         return [(h, self[h]) for h in self.keys()]
 
+    @_locked_g
     def clear(self) -> None:
         for h in self.keys():
             self.pop(h, None)
@@ -219,6 +260,7 @@ class ContextGraph:
     """Truth-maintenance flavored graph (v1) -- GPU-ranked drop-in (lb/context_graph.py:46-148)."""
 
     def __init__(self) -> None:
+        self._lock = threading.RLock()
         self._dirty: Dict[str, None] = {}      # insertion-ordered set of hashes to reconcile
         self._pending_text: Dict[str, str] = {}  # text captured by add_claim (embedded at next sync)
         self._id_of: Dict[str, int] = {}       # hash -> device claim id (rows the GPU scans)
@@ -244,6 +286,7 @@ class ContextGraph:
             self._index_obj = _hip.Index()  # raises HipBackendError without liblbhip.so + MI355X
         return self._index_obj
 
+    @_locked
     def _touch(self, h: str) -> None:
         self._dirty[h] = None
 
@@ -268,6 +311,7 @@ class ContextGraph:
         self._keys_stale = True
         return b"\x00" * _hip.KEY_BYTES  # placeholder until _refresh_rank_keys
 
+    @_locked
     def _refresh_rank_keys(self) -> None:
         hs = sorted(self._id_of.keys())  # Python str order: what lb/context_graph.py:120 compares
         if hs:
@@ -278,6 +322,7 @@ class ContextGraph:
             self._index.set_keys(ids, keys)
         self._keys_stale = False
 
+    @_locked
     def _drop_row(self, h: str, park: bool) -> None:
         cid = self._id_of.pop(h, None)
         if cid is None:
@@ -288,6 +333,7 @@ class ContextGraph:
         self._hash_of.pop(cid, None)
         self._meta.pop(h, None)
 
+    @_locked
     def _sync(self) -> None:
         """Bring the device index in line with ``claims`` (only dirty hashes are looked at)."""
         if not self._dirty:
@@ -355,6 +401,7 @@ class ContextGraph:
 
     # ------------------------------------------------------------------ reference API
 
+    @_locked
     def add_claim(
         self,
         claim_hash: str,
@@ -381,6 +428,7 @@ class ContextGraph:
             retracted=False,
         )
 
+    @_locked
     def retract(self, claim_hash: str) -> None:
         c = self.claims.get(claim_hash)
         if c:
@@ -439,6 +487,7 @@ class ContextGraph:
                 return since, 0, True  # no claim carries any of the requested tags
         return since, tag_mask, False
 
+    @_locked
     def _rank(self, query, top_k, since_ms, tags, stats=None) -> Tuple[List[str], List[float]]:
         self._sync()
         k = max(0, int(top_k))  # :121
@@ -451,6 +500,7 @@ class ContextGraph:
         ids, scores, _ = index.search_text(query, k, since, tag_mask, stats)
         return [self._hash_of[i] for i in ids.tolist()], scores.tolist()
 
+    @_locked
     def recent(self, since_ms, limit: Optional[int] = 100) -> List[str]:
         """Claim hashes of ``BatteryNode.get_recent_claims`` (lb/node.py:750-762) in the reference's order:
         live claims with ``created_ms >= since_ms``, newest first, ties in ``claims`` dict order, then
@@ -490,6 +540,7 @@ class ContextGraph:
         ids, _, _ = index.recent(since, want)
         return [self._hash_of[i] for i in ids.tolist()]
 
+    @_locked
     def compile_many(self, queries: Sequence[str], *, top_k: int = 8, since_ms: Optional[int] = None,
                      tags: Optional[Sequence[str]] = None) -> List[Tuple[str, List[str]]]:
         """Batched ``compile`` (extension; the reference has no batched entry): the queries are embedded
@@ -508,6 +559,7 @@ class ContextGraph:
             ranked = [[self._hash_of[i] for i in ids[j, : int(cnt[j])].tolist()] for j in range(len(queries))]
         return [(self._format(q, chosen), chosen) for q, chosen in zip(queries, ranked)]
 
+    @_locked
     def snapshot(self) -> Dict[str, Any]:
         return {"claims": {h: c.to_dict() for h, c in self.claims.items()}}
 

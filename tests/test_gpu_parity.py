@@ -243,6 +243,59 @@ def test_randomised_incremental_ops_vs_oracle(hip, seed, hex_hashes):
     assert n_queries > 100
 
 
+def test_queries_overlap_publishes_from_another_thread(hip):
+    """compile_context takes no lock in the reference while writers publish (lb/node.py:718 vs :465): a reader
+    thread must never crash or see a half-updated mirror, and once the writer is done the graph must answer
+    exactly like the oracle fed with the same operations."""
+    import threading
+    from lbm_amd.context_graph import ContextGraph
+    g, og = ContextGraph(), orc.OracleGraph()
+    ops = []
+    for i in range(1500):
+        ops.append(("add", "h%05d" % i, "alpha beta gamma delta eps zeta".split()[i % 6] + " w%d x%d" % (i % 17, i % 5), i))
+        if i % 7 == 3:
+            ops.append(("retract", "h%05d" % (i - 2), None, None))
+    errors, done = [], threading.Event()
+
+    def writer():
+        try:
+            for op, h, text, ms in ops:
+                if op == "add":
+                    g.add_claim(h, text, ["t"], created_ms=ms)
+                else:
+                    g.retract(h)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+        finally:
+            done.set()
+
+    def reader():
+        try:
+            n = 0
+            while not done.is_set() or n < 50:
+                text, hashes = g.compile("alpha w3", top_k=5)
+                assert len(hashes) <= 5 and text.startswith("Context slice")
+                assert len(g.recent(0, 7)) <= 7
+                n += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=writer), threading.Thread(target=reader), threading.Thread(target=reader)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not errors, errors
+    for op, h, text, ms in ops:
+        if op == "add":
+            og.add_claim(h, text, ["t"], created_ms=ms)
+        else:
+            og.retract(h)
+    for q, kw in (("alpha w3", {"top_k": 5}), ("zeta x1 w16", {"top_k": 20, "since_ms": 700}), ("", {"top_k": 3})):
+        assert g.compile(q, **kw) == og.compile(q, **kw)
+    assert g.recent(1000, 50) == [c["claim_hash"] for c in orc.recent_claims(og.claims, 1000, 50)]
+
+
 def _arrays_case(n, seed, dup_frac=0.002):
     from lbm_amd import synth
     ch = synth.make_chunk(0, n, seed=seed, real_sha_keys=False, dup_frac=dup_frac)
