@@ -42,7 +42,6 @@ struct lbh_ctx {
     int device = 0;
     int n_cu = 256;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::string arch;
     int scan_blocks_per_cu = 2;  // tuning knobs (env LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT), see DESIGN.md
     int scan_nt = 1;
@@ -75,6 +74,7 @@ struct lbh_index {
     lbh_qarg qarg{};              // current query when it came from the host (kernel argument)
     const double* qptr = nullptr;  // current query when it was embedded on the GPU (ws.q64), else NULL
     int32_t seq = 0;          // completion ticket of the last single-query launch
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // per index: searches on two indexes may run concurrently
     void* staging = nullptr;  // pinned host staging
     int64_t staging_cap = 0;
 };
@@ -208,7 +208,7 @@ int run_page(lbh_index* ix, int page, int64_t since_ms, uint64_t tag_mask, bool 
     const int grid = lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu);
     bool fast = allow_fast && !cur.active;
     for (;;) {
-        hipEvent_t e0 = timing ? c->ev[0] : nullptr, e1 = timing ? c->ev[1] : nullptr;
+        hipEvent_t e0 = timing ? ix->ev[0] : nullptr, e1 = timing ? ix->ev[1] : nullptr;
         const int32_t seq = ix->seq = (ix->seq == INT32_MAX) ? 1 : ix->seq + 1;
         if (fast)
             HIP_TRY(lbh_launch_search_fast(dv, ix->ws, ix->qptr, ix->qarg, page, has_since, since_ms, tag_mask, grid, c->scan_nt, seq, s, e0, e1));
@@ -218,12 +218,12 @@ int run_page(lbh_index* ix, int page, int64_t since_ms, uint64_t tag_mask, bool 
         }
         const lbh_result* r = ix->ws.result_host;
         HIP_TRY(wait_ticket(c, &r->seq, seq));
-        if (timing) HIP_TRY(hipEventSynchronize(c->ev[1]));
+        if (timing) HIP_TRY(hipEventSynchronize(ix->ev[1]));
         acc->scan_launches += 1;
         acc->rows_scanned = ix->n;
         if (timing) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) acc->scan_ms += ms;
+            if (hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]) == hipSuccess) acc->scan_ms += ms;
         }
         if (fast) {
             acc->path = 0;
@@ -257,7 +257,7 @@ int search_loaded(lbh_index* ix, int64_t k, int64_t since_ms, uint64_t tag_mask,
     SearchAcc acc;
     int64_t got = 0;
     const bool timing_total = timing && stats->want_timing >= 2;  // two more event records per call
-    if (timing_total) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    if (timing_total) HIP_TRY(hipEventRecord(ix->ev[2], c->stream));
     if (k > 0 && ix->n > 0) {
         lbh_cursor cur;
         memset(&cur, 0, sizeof cur);
@@ -285,9 +285,9 @@ int search_loaded(lbh_index* ix, int64_t k, int64_t since_ms, uint64_t tag_mask,
     if (stats) {
         float total = 0.f;
         if (timing_total) {
-            HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-            HIP_TRY(hipEventSynchronize(c->ev[3]));
-            (void)hipEventElapsedTime(&total, c->ev[2], c->ev[3]);
+            HIP_TRY(hipEventRecord(ix->ev[3], c->stream));
+            HIP_TRY(hipEventSynchronize(ix->ev[3]));
+            (void)hipEventElapsedTime(&total, ix->ev[2], ix->ev[3]);
         }
         stats->path = acc.path;
         stats->rows_scanned = acc.rows_scanned;
@@ -370,7 +370,6 @@ int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx) {
     if (const char* e3 = getenv("LBH_SPIN_US")) c->spin_us = std::max(0, std::min(1000000, atoi(e3)));
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (auto& ev : c->ev) HIP_TRY(hipEventCreate(&ev));
     *out_ctx = c;
     return LBH_OK;
 }
@@ -382,8 +381,6 @@ int lbh_shutdown(lbh_ctx* c) {
     if (c->d_text) (void)hipFree(c->d_text);
     if (c->d_off) (void)hipFree(c->d_off);
     if (c->d_vec) (void)hipFree(c->d_vec);
-    for (auto& ev : c->ev)
-        if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return LBH_OK;
@@ -473,6 +470,7 @@ int index_alloc_workspace(lbh_index* ix) {
     HIP_TRY(hipHostGetDevicePointer((void**)&w.result_dev, w.result_host, 0));
     memset(w.result_host, 0, sizeof(lbh_result));
     HIP_TRY(hipMemset(w.flags, 0, 256));
+    for (auto& ev : ix->ev) HIP_TRY(hipEventCreate(&ev));
     return LBH_OK;
 }
 }  // namespace
@@ -504,6 +502,8 @@ int lbh_index_destroy(lbh_index* ix) {
                    w.flags, w.bq_qmat, w.bq_cand, w.bq_total, w.bq_seed};
     for (void* p : dev)
         if (p) (void)hipFree(p);
+    for (auto& ev : ix->ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (w.result_host) (void)hipHostFree(w.result_host);
     if (w.bq_result_host) (void)hipHostFree(w.bq_result_host);
     if (w.rc_result_host) (void)hipHostFree(w.rc_result_host);
@@ -699,12 +699,12 @@ int lbh_index_recent(lbh_index* ix, int64_t since_ms, int64_t limit, uint64_t* o
         const int page = (int)std::max<int64_t>(1, std::min<int64_t>(remaining, LBH_MAX_PAGE));
         const int32_t seq = ix->seq = (ix->seq == INT32_MAX) ? 1 : ix->seq + 1;
         HIP_TRY(lbh_launch_recent(ix->created, ix->order, ix->n, ix->ws, page, has_since, since_ms, cur, anchor, c->n_cu, seq,
-                                  c->stream, timing ? c->ev[0] : nullptr, timing ? c->ev[1] : nullptr));
+                                  c->stream, timing ? ix->ev[0] : nullptr, timing ? ix->ev[1] : nullptr));
         HIP_TRY(wait_ticket(c, &r->seq, seq));
         if (timing) {
-            HIP_TRY(hipEventSynchronize(c->ev[1]));
+            HIP_TRY(hipEventSynchronize(ix->ev[1]));
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) stats->scan_ms += ms;
+            if (hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]) == hipSuccess) stats->scan_ms += ms;
         }
         if (stats) {
             stats->scan_launches += 1;
@@ -807,13 +807,13 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
             const int nb = (int)std::min<int64_t>(LBH_BQ_MAXQ, nq - q0);
             HIP_TRY(hipMemcpyAsync(ix->ws.bq_qmat, q_f64 + q0 * 64, (size_t)nb * 512, hipMemcpyHostToDevice, s));
             HIP_TRY(lbh_launch_search_batched(dv, ix->ws, nb, (int)keff, has_since, since_ms, tag_mask, c->n_cu, c->bq_mode, s,
-                                              timing ? c->ev[0] : nullptr, timing ? c->ev[1] : nullptr));
+                                              timing ? ix->ev[0] : nullptr, timing ? ix->ev[1] : nullptr));
             HIP_TRY(hipStreamSynchronize(s));
             total.scan_launches += 1;
             total.rows_scanned += ix->n;
             if (timing) {
                 float ms = 0.f;
-                if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) total.scan_ms += ms;
+                if (hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]) == hipSuccess) total.scan_ms += ms;
             }
             for (int i = 0; i < nb; ++i) {
                 const lbh_result* r = ix->ws.bq_result_host + i;
