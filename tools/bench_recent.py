@@ -14,7 +14,14 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lbm_amd import _hip  # noqa: E402
-from oracle import lb_oracle as orc  # noqa: E402  (CPU baseline leg only)
+
+
+def numpy_recent(created, order, since, limit):
+    """The same answer on one host core with numpy (timing reference only; parity is tests/test_recent.py)."""
+    idx = np.nonzero(created >= since)[0]
+    by_order = idx[np.argsort(order[idx], kind="stable")][::-1]
+    asc = by_order[np.argsort(created[by_order], kind="stable")]
+    return asc[::-1][:limit]
 
 
 def main():
@@ -41,7 +48,7 @@ def main():
     for name, since, limit in [("limit100", _hip.SINCE_NONE, 100), ("limit100_since_p90", p90, 100),
                                ("limit1000", _hip.SINCE_NONE, 1000), ("limit64", _hip.SINCE_NONE, 64)]:
         ids, cr, matched = ix.recent(since, limit)
-        exp = orc.recent_arrays(created, order, since, limit)
+        exp = numpy_recent(created, order, since, limit)
         assert ids.tolist() == exp.tolist() and cr.tolist() == created[exp].tolist()
         wall, scan = [], []
         for r in range(args.reps):
@@ -52,7 +59,7 @@ def main():
             if r % 4 == 0:
                 scan.append(st.scan_ms * 1e-3 / st.scan_launches)
         t0 = time.perf_counter()
-        orc.recent_arrays(created, order, since, limit)
+        numpy_recent(created, order, since, limit)
         t_cpu = time.perf_counter() - t0
         s = float(np.median(scan))
         out[name] = {"limit": limit, "matched": matched, "passes": st.scan_launches,
