@@ -238,7 +238,7 @@ int run_page(lbh_index* ix, int page, int64_t since_ms, uint64_t tag_mask, bool 
             continue;
         }
         if (r->overflow)
-            return fail(LBH_E_INTERNAL, "exact path: more than %d claims tie on score and on the first 8 key bytes", LBH_MCAP);
+            return fail(LBH_E_INTERNAL, "exact path: more than %d claims tie on score AND carry the same 32-byte hash key (keys must be unique)", LBH_MCAP);
         acc->candidates += r->candidates;
         if (fast) acc->max_err = std::max(acc->max_err, r->max_err);
         out->count = r->count;

@@ -1193,8 +1193,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_exact_kernel(lbh_dev_index
     uint32_t* xr = reinterpret_cast<uint32_t*>(sbuf + LBH_MCAP);
 
     uint64_t kth = 0;       // admit everything unless there are more entries than the final sort holds
-    uint64_t key0_cut = ~0ull;
-    bool use_key_cut = false;
+    uint64_t cut[4] = {~0ull, ~0ull, ~0ull, ~0ull};  // mass tie on the k-th score: the tie group is cut by the hash key,
+    int ncut = 0;                                     // one 64-bit word at a time (ascending), until what is left fits
     if (E > LBH_MCAP) {
         auto val = [&](int e, uint64_t* v) { *v = xc_ord[e]; return true; };
         kth = block_radix_select(E, 8, k, val, hist, &sh_krem, &sh_bin);
@@ -1207,23 +1207,51 @@ __global__ __launch_bounds__(SEL_THREADS) void select_exact_kernel(lbh_dev_index
         if (gt) atomicAdd(&sh_gt, gt);
         if (eq) atomicAdd(&sh_eq, eq);
         __syncthreads();
-        if (sh_gt + sh_eq > LBH_MCAP) {
-            // mass tie on the k-th score: cut the tie group by the first key word (ascending)
-            const int64_t need = k - sh_gt;
+        int64_t kept = sh_gt;            // entries that are certainly in
+        int64_t need = k - sh_gt;        // how many of the current tie group are wanted (>= 1)
+        bool fits = sh_gt + sh_eq <= LBH_MCAP;
+        for (int w = 0; w < 4 && !fits; ++w) {
+            // among the entries that tie on the score and on key words 0..w-1: the need-th smallest word w
             auto kval = [&](int e, uint64_t* v) {
                 if (xc_ord[e] != kth) return false;
-                *v = ~ix.keys[(size_t)xc_row[e] * 4];
+                const uint64_t* kp = ix.keys + (size_t)xc_row[e] * 4;
+                for (int j2 = 0; j2 < w; ++j2)
+                    if (kp[j2] != cut[j2]) return false;
+                *v = ~kp[w];
                 return true;
             };
-            key0_cut = ~block_radix_select(E, 8, need, kval, hist, &sh_krem, &sh_bin);
-            use_key_cut = true;
+            cut[w] = ~block_radix_select(E, 8, need, kval, hist, &sh_krem, &sh_bin);
+            ncut = w + 1;
+            __syncthreads();
+            if (tid == 0) { sh_gt = 0; sh_eq = 0; }   // re-used: group members below / at the cut word
+            __syncthreads();
+            int lt = 0, eqw = 0;
+            for (int e = tid; e < E; e += SEL_THREADS) {
+                uint64_t v;
+                if (kval(e, &v)) {
+                    lt += ~v < cut[w];
+                    eqw += ~v == cut[w];
+                }
+            }
+            if (lt) atomicAdd(&sh_gt, lt);
+            if (eqw) atomicAdd(&sh_eq, eqw);
+            __syncthreads();
+            fits = kept + sh_gt + sh_eq <= LBH_MCAP;  // keeping everything up to and including the cut word fits
+            kept += sh_gt;
+            need -= sh_gt;
+            __syncthreads();
         }
     }
     for (int e = tid; e < E; e += SEL_THREADS) {
         const uint64_t o = xc_ord[e];
         const uint32_t r = xc_row[e];
         bool in = o >= kth;
-        if (in && use_key_cut && o == kth) in = ix.keys[(size_t)r * 4] <= key0_cut;
+        if (in && ncut && o == kth) {  // lexicographic: key words 0..ncut-1 <= cut
+            const uint64_t* kp = ix.keys + (size_t)r * 4;
+            for (int w = 0; w < ncut; ++w) {
+                if (kp[w] != cut[w]) { in = kp[w] < cut[w]; break; }
+            }
+        }
         if (in) {
             const int pos = atomicAdd(&sh_cnt, 1);
             if (pos < LBH_MCAP) { xo[pos] = o; xr[pos] = r; }
