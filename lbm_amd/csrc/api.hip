@@ -2,6 +2,7 @@
 // points declared in include/lbhip.h.  No compute happens here: every number the caller sees was
 // produced by a kernel in embed.hip / search.hip.  There is no CPU fallback.
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -73,6 +74,8 @@ struct lbh_index {
     lbh_workspace ws{};
     lbh_qarg qarg{};              // current query when it came from the host (kernel argument)
     const double* qptr = nullptr;  // current query when it was embedded on the GPU (ws.q64), else NULL
+    double max_norm = 0.0;    // largest |x| ever added: the scans' error bounds (hence their candidate margins) scale with it
+    double qnorm = 1.0;       // |q| of the current query (1 for a query embedded from text)
     int32_t seq = 0;          // completion ticket of the last single-query launch
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // per index: searches on two indexes may run concurrently
     void* staging = nullptr;  // pinned host staging
@@ -165,6 +168,19 @@ inline void store_be64(uint8_t* p, uint64_t v) {
     memcpy(p, &v, 8);
 }
 
+double vec_norm(const double* v) {
+    double s = 0.0;
+    for (int d = 0; d < LBH_DIM; ++d) s += v[d] * v[d];
+    return std::sqrt(s);
+}
+
+// |scan score - exact score| <= eps * |x| * |q|; the reference's embeddings are unit vectors (or zero), but vectors
+// handed in directly (lbh_index_add with emb_f64, ContextGraph._embedding_cache[h] = v) and query vectors need not be
+float norm_scale(const lbh_index* ix, double qnorm) {
+    const double s = ix->max_norm * qnorm * (1.0 + 1e-6);
+    return (float)std::min(std::max(s, 1e-30), 1e30);
+}
+
 // Latency path: the final kernel of a query writes its result block into mapped host memory and
 // publishes the ticket last, so polling it skips the runtime's completion hand-off.  Bounded: past
 // spin_us (a hung or faulted kernel, or a very long scan) fall back to the stream, which also reports
@@ -211,7 +227,8 @@ int run_page(lbh_index* ix, int page, int64_t since_ms, uint64_t tag_mask, bool 
         hipEvent_t e0 = timing ? ix->ev[0] : nullptr, e1 = timing ? ix->ev[1] : nullptr;
         const int32_t seq = ix->seq = (ix->seq == INT32_MAX) ? 1 : ix->seq + 1;
         if (fast)
-            HIP_TRY(lbh_launch_search_fast(dv, ix->ws, ix->qptr, ix->qarg, page, has_since, since_ms, tag_mask, grid, c->scan_nt, seq, s, e0, e1));
+            HIP_TRY(lbh_launch_search_fast(dv, ix->ws, ix->qptr, ix->qarg, page, has_since, since_ms, tag_mask, grid, c->scan_nt, seq,
+                                           LBH_MARGIN * norm_scale(ix, ix->qnorm), s, e0, e1));
         else {
             const int xgrid = std::min(grid, 512);
             HIP_TRY(lbh_launch_search_exact(dv, ix->ws, ix->qptr, ix->qarg, page, has_since, since_ms, tag_mask, cur, xgrid, seq, s, e0, e1));
@@ -332,8 +349,11 @@ int ensure_recent_ws(lbh_index* ix) {
 }
 
 int load_query(lbh_index* ix, const double* q) {
+    const double nrm = vec_norm(q);
+    if (!(nrm <= 1e15)) return fail(LBH_E_INVALID, "query vector is not finite (or its norm exceeds 1e15)");
     memcpy(ix->qarg.q, q, sizeof ix->qarg.q);  // travels to the GPU inside the kernel-argument segment
     ix->qptr = nullptr;
+    ix->qnorm = nrm;
     return LBH_OK;
 }
 
@@ -548,7 +568,11 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
     HIP_TRY(hipMemcpyAsync(ix->tags + r0, h_tags, (size_t)n * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(ix->keys + r0 * 4, h_keys, (size_t)n * 32, hipMemcpyHostToDevice, s));
     HIP_TRY(lbh_launch_iota_u64(ix->order + r0, (uint64_t)ix->row_of_id.size(), n, s));
+    double batch_norm = 1.0;  // K1 writes unit vectors (or zero)
     if (emb_f64) {
+        batch_norm = 0.0;
+        for (int64_t i = 0; i < n; ++i) batch_norm = std::max(batch_norm, vec_norm(emb_f64 + i * 64));
+        if (!(batch_norm <= 1e15)) return fail(LBH_E_INVALID, "a vector is not finite (or its norm exceeds 1e15)");
         HIP_TRY(hipMemcpyAsync(ix->emb64 + r0 * 64, emb_f64, (size_t)n * 512, hipMemcpyHostToDevice, s));
         HIP_TRY(lbh_launch_f64_to_f32(ix->emb64 + r0 * 64, ix->emb32 + r0 * 64, n * 64, s));
     } else {
@@ -583,6 +607,7 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
         if (out_ids) out_ids[i] = id0 + (uint64_t)i;
     }
     ix->n += n;
+    ix->max_norm = std::max(ix->max_norm, batch_norm);
     return LBH_OK;
 }
 
@@ -805,8 +830,12 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
         const int has_since = since_ms != LBH_SINCE_NONE;
         for (int64_t q0 = 0; q0 < nq; q0 += LBH_BQ_MAXQ) {
             const int nb = (int)std::min<int64_t>(LBH_BQ_MAXQ, nq - q0);
+            double qn = 0.0;
+            for (int q = 0; q < nb; ++q) qn = std::max(qn, vec_norm(q_f64 + (q0 + q) * 64));
+            if (!(qn <= 1e15)) return fail(LBH_E_INVALID, "a query vector is not finite (or its norm exceeds 1e15)");
             HIP_TRY(hipMemcpyAsync(ix->ws.bq_qmat, q_f64 + q0 * 64, (size_t)nb * 512, hipMemcpyHostToDevice, s));
-            HIP_TRY(lbh_launch_search_batched(dv, ix->ws, nb, (int)keff, has_since, since_ms, tag_mask, c->n_cu, c->bq_mode, s,
+            HIP_TRY(lbh_launch_search_batched(dv, ix->ws, nb, (int)keff, has_since, since_ms, tag_mask, c->n_cu, c->bq_mode,
+                                              norm_scale(ix, qn), s,
                                               timing ? ix->ev[0] : nullptr, timing ? ix->ev[1] : nullptr));
             HIP_TRY(hipStreamSynchronize(s));
             total.scan_launches += 1;
@@ -891,6 +920,7 @@ int lbh_index_search_text(lbh_index* ix, const uint8_t* utf8, int64_t len, int64
         // embed(query) (lb/context_graph.py:104) straight into the search workspace
         HIP_TRY(lbh_launch_embed(c->d_text, c->d_off, 1, ix->ws.q64, nullptr, s));
         ix->qptr = ix->ws.q64;
+        ix->qnorm = 1.0;  // K1 output: a unit vector (or zero)
         if (out_qvec64) {
             HIP_TRY(hipMemcpyAsync(out_qvec64, ix->ws.q64, 512, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));

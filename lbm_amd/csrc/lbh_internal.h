@@ -139,7 +139,7 @@ hipError_t lbh_launch_scatter_u64(uint64_t* dst, const int64_t* rows_dev, const 
 int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu);
 hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
                                   const lbh_qarg& qa, int k, int has_since,
-                                  int64_t since_ms, uint64_t tag_mask, int grid, int nt, int seq,
+                                  int64_t since_ms, uint64_t tag_mask, int grid, int nt, int seq, float margin,
                                   hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
                                    const lbh_qarg& qa, int k, int has_since,
@@ -149,5 +149,5 @@ hipError_t lbh_launch_recent(const int64_t* created, const uint64_t* order, int6
                              int page, int has_since, int64_t since_ms, const lbh_rcursor& cur, int64_t anchor_row,
                              int n_cu, int seq, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspace& ws, int nq, int k, int has_since,
-                                     int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, hipStream_t s,
+                                     int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, float norm_scale, hipStream_t s,
                                      hipEvent_t ev0, hipEvent_t ev1);

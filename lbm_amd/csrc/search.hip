@@ -119,7 +119,7 @@ __device__ __forceinline__ double exact_dot(const double* __restrict__ q, const 
 // ------------------------------------------------------------------------------------------------
 template <bool SINCE, bool TAGS, bool NT>
 __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_index ix, const double* __restrict__ qptr, lbh_qarg qa,
-                                                                     int k, int64_t since_ms, uint64_t tag_mask,
+                                                                     int k, float margin, int64_t since_ms, uint64_t tag_mask,
                                                                      uint64_t* __restrict__ cand,
                                                                      int32_t* __restrict__ flags) {
     __shared__ uint64_t wbuf[LBH_SCAN_WAVES][LBH_WCAP];
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
         sort_desc_u64(buf, n2, lane, 64, WaveSync());
         if (cnt >= k) {
             const uint32_t kth = (uint32_t)(buf[k - 1] >> 32);
-            const uint32_t nt = lbh_ord32(lbh_unord32(kth) - LBH_MARGIN);
+            const uint32_t nt = lbh_ord32(lbh_unord32(kth) - margin);
             if (nt > thr) thr = nt;
             int kept = 0;
             for (int i = lane; i < n2; i += 64)
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
     if (total == 0) return;
     sort_desc_u64(mbuf, n2, threadIdx.x, LBH_SCAN_THREADS, BlockSync());
     uint32_t bthr = 0;
-    if (total >= k) bthr = lbh_ord32(lbh_unord32((uint32_t)(mbuf[k - 1] >> 32)) - LBH_MARGIN);
+    if (total >= k) bthr = lbh_ord32(lbh_unord32((uint32_t)(mbuf[k - 1] >> 32)) - margin);
     // survivors are a prefix of the sorted array; they go to one flat candidate array in HBM
     __shared__ int nsurv, gbase;
     if (threadIdx.x == 0) nsurv = 0;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index 
                                                                    lbh_qarg qa, int k,
                                                                    const uint64_t* __restrict__ cand,
                                                                    int32_t* __restrict__ flags,
-                                                                   lbh_result* __restrict__ res, int seq) {
+                                                                   lbh_result* __restrict__ res, int seq, float margin) {
     __shared__ double qs[64];
     const int tid = threadIdx.x;
     const int overflowed = flags[0];
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index 
     if (overflowed) {
         if (tid == 0) { res->count = 0; res->overflow = 1; res->candidates = 0; }
     } else {
-        select_fast_body(ix, qs, k, cand, E, res, LBH_MARGIN);
+        select_fast_body(ix, qs, k, cand, E, res, margin);
     }
     publish_result(res, seq);
 }
@@ -657,7 +657,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <bool SINCE, bool TAGS, bool BF16>
 __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index ix, const double* __restrict__ qmat,
-                                                                   int nq, int k, int64_t since_ms, uint64_t tag_mask,
+                                                                   int nq, int k, float margin, int64_t since_ms, uint64_t tag_mask,
                                                                    int64_t row_begin, int64_t row_end,
                                                                    const uint32_t* __restrict__ seed,
                                                                    uint64_t* __restrict__ cand3,
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
     bq_ctx bc;
     bc.qbuf = qbuf; bc.qcnt = qcnt; bc.qthr = qthr; bc.qtotal = qtotal;
     bc.k = k; bc.lane = lane; bc.wave = wave; bc.myq = myq; bc.h = h; bc.qactive = qactive;
-    bc.margin = BF16 ? LBH_MARGIN_BF16X3 : LBH_MARGIN;
+    bc.margin = margin;
 
     // rows of one 32-claim tile that pass the since / tag filters, as one word (lanes 0..31 vote)
     auto row_mask = [&](int64_t row0) -> uint32_t {
@@ -909,7 +909,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 template <bool SINCE, bool TAGS>
 __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_index ix, const double* __restrict__ qmat,
-                                                                       int nq, int k, int64_t since_ms, uint64_t tag_mask,
+                                                                       int nq, int k, float margin, int64_t since_ms, uint64_t tag_mask,
                                                                        int64_t row_begin, int64_t row_end,
                                                                        const uint32_t* __restrict__ seed,
                                                                        uint64_t* __restrict__ cand3,
@@ -958,7 +958,7 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_in
     bq_ctx bc;
     bc.qbuf = qbuf; bc.qcnt = qcnt; bc.qthr = qthr; bc.qtotal = qtotal;
     bc.k = k; bc.lane = lane; bc.wave = wave; bc.myq = myq; bc.h = h; bc.qactive = qactive;
-    bc.margin = LBH_MARGIN_F16;
+    bc.margin = margin;
     auto row_mask = [&](int64_t row0) -> uint32_t {
         bool rv = false;
         if (lane < 32) {
@@ -1578,12 +1578,12 @@ int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu) {
 
 hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
                                   const lbh_qarg& qa, int k, int has_since,
-                                  int64_t since_ms, uint64_t tag_mask, int grid, int nt, int seq,
+                                  int64_t since_ms, uint64_t tag_mask, int grid, int nt, int seq, float margin,
                                   hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     hipError_t e;
     if (ev0) (void)hipEventRecord(ev0, s);
     const dim3 g(grid), b(LBH_SCAN_THREADS);
-#define LBH_SCAN_ARGS ix, qptr, qa, k, since_ms, tag_mask, ws.cand, ws.flags
+#define LBH_SCAN_ARGS ix, qptr, qa, k, margin, since_ms, tag_mask, ws.cand, ws.flags
     if (nt) {
         if (has_since && tag_mask) scan_f32_kernel<true, true, true><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
         else if (has_since) scan_f32_kernel<true, false, true><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
@@ -1599,7 +1599,7 @@ hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const lbh_workspace& 
     if (ev1) (void)hipEventRecord(ev1, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, qptr, qa, k, ws.cand, ws.flags, ws.result_dev, seq);
+    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, qptr, qa, k, ws.cand, ws.flags, ws.result_dev, seq, margin);
     return hipGetLastError();
 }
 
@@ -1624,8 +1624,8 @@ hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace&
 }
 
 hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspace& ws, int nq, int k, int has_since,
-                                     int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, hipStream_t s, hipEvent_t ev0,
-                                     hipEvent_t ev1) {
+                                     int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, float norm_scale, hipStream_t s,
+                                     hipEvent_t ev0, hipEvent_t ev1) {
     // one-time set-up (thread-safe: searches on different indexes may arrive concurrently)
     static std::once_flag once;
     static hipError_t once_err = hipSuccess;
@@ -1655,7 +1655,10 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspac
     });
     if (once_err != hipSuccess) return once_err;
     hipError_t e;
-    const float margin = bf16 == 2 ? LBH_MARGIN_F16 : bf16 ? LBH_MARGIN_BF16X3 : LBH_MARGIN;
+    // the error bounds are relative to |x||q| (1 for the reference's unit vectors); fp16 additionally needs the
+    // components inside its range, so anything but unit-scale data takes the split-bf16 kernel instead
+    if (bf16 == 2 && (norm_scale > 1.001f || norm_scale < 0.25f)) bf16 = 1;
+    const float margin = (bf16 == 2 ? LBH_MARGIN_F16 : bf16 ? LBH_MARGIN_BF16X3 : LBH_MARGIN) * norm_scale;
     e = hipMemsetAsync(ws.flags, 0, 16, s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws.bq_total, 0, BQ_MAXQ * 4, s);
@@ -1664,7 +1667,7 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspac
     auto launch = [&](int64_t r0, int64_t r1, const uint32_t* seed) {
         const int64_t tiles = (r1 - r0 + 63) / 64;
         const dim3 g((unsigned)(tiles < n_cu ? tiles : n_cu));
-#define LBH_BSCAN_ARGS ix, ws.bq_qmat, nq, k, since_ms, tag_mask, r0, r1, seed, ws.bq_cand, ws.bq_total, ws.flags
+#define LBH_BSCAN_ARGS ix, ws.bq_qmat, nq, k, margin, since_ms, tag_mask, r0, r1, seed, ws.bq_cand, ws.bq_total, ws.flags
         if (bf16 == 2) {  // one fp16 product per k-step
             if (has_since && tag_mask) scan_batched_f16_kernel<true, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
             else if (has_since) scan_batched_f16_kernel<true, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);

@@ -6,7 +6,8 @@ bits with ``oracle.compile_arrays``.  Vectors come in three kinds so that the ne
 text embeddings (the product's real distribution), clustered random vectors (many near-ties) and vectors
 quantised to a few levels (many exact ties, broken by the hash key).  LBM_FUZZ_ROUNDS scales the run
 (default 12, a few seconds; the round-1 campaign ran 400 rounds with LBM_FUZZ_BIG=1, which adds 300 k-claim
-corpora).  Found so far: the exact path's mass-tie cut stopped at the first key word (fixed: all four).
+corpora).  Found so far: the exact path's mass-tie cut stopped at the first key word (fixed: all four);
+candidate margins assumed unit vectors (fixed: they scale with the largest |x| ever added times |q|).
 """
 import os
 
@@ -35,6 +36,7 @@ def _corpus(rng, n, kind):
         v = rng.integers(-1, 2, size=(n, 64)).astype(np.float64)
         v[np.all(v == 0, axis=1)] = 1.0
     v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v *= float(rng.choice([1.0, 1.0, 1.0, 0.01, 37.5]))  # vectors handed in directly need not be unit vectors
     keys = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
     if rng.random() < 0.5:  # hashes that share a 28-byte prefix and differ only at the very end
         keys[:, :28] = keys[0, :28]
@@ -65,10 +67,13 @@ def test_search_paths_vs_oracle(seed):
     nq = int(rng.choice([1, 3, 17, 40]))
     q = rng.standard_normal((nq, 64))
     pick = rng.integers(0, n, size=nq)
-    q[: nq // 2] = emb[pick[: nq // 2]] + 1e-3 * rng.standard_normal((nq // 2, 64))  # queries that sit on claims
+    q[: nq // 2] = emb[pick[: nq // 2]] / np.maximum(np.linalg.norm(emb[pick[: nq // 2]], axis=1, keepdims=True), 1e-300) \
+        + 1e-3 * rng.standard_normal((nq // 2, 64))  # queries that sit on claims
     if nq > 2:
         q[-1] = 0.0  # the empty query: every score 0.0
     q /= np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-300)
+    q *= float(rng.choice([1.0, 1.0, 1.0, 1e-3, 250.0]))
+    unit = abs(float(np.linalg.norm(emb, axis=1).max()) - 1.0) < 1e-9 and abs(float(np.linalg.norm(q, axis=1).max()) - 1.0) < 1e-9
     k = int(rng.choice([1, 2, 8, 16, 64, 90]))
     since = None if rng.random() < 0.5 else int(rng.integers(0, 55))
     tmask = 0 if rng.random() < 0.6 else int(rng.integers(1, 256))
@@ -78,12 +83,12 @@ def test_search_paths_vs_oracle(seed):
         gi, gs, _ = ix.search_shard(q[j], k, hip.SINCE_NONE if since is None else since, tmask, st)
         assert ids[want[j][0]].tolist() == gi.tolist(), ("single", seed, j, kind, n, k, since, tmask)
         assert want[j][1].tobytes() == gs.tobytes(), ("single", seed, j)
-        if st.path == 0:
+        if st.path == 0 and unit:
             assert st.max_score_err < 5e-6
     for mode, margin in ((2, 2.2e-3), (1, 1e-4), (0, 1e-5)):  # batched path in each scan precision
         hip.set_option("bq_mode", mode)
         gi, gs, cnt = ix.search(q, k, hip.SINCE_NONE if since is None else since, tmask, st)
-        if st.path == 2:
+        if st.path == 2 and unit:
             assert st.max_score_err < margin / 2, (mode, st.max_score_err)
         for j in range(nq):
             m = int(cnt[j])
