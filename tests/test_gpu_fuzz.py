@@ -96,3 +96,33 @@ def test_search_paths_vs_oracle(seed):
             assert want[j][1].tobytes() == gs[j, :m].tobytes(), ("batched", mode, seed, j)
     hip.set_option("bq_mode", 2)
     ix.close()
+
+
+@pytest.mark.parametrize("seed", range(max(1, ROUNDS // 4)))
+def test_embed_random_bytes_vs_oracle(seed):
+    """K1 against the oracle on adversarial text shapes: token lengths around the SHA-256 padding boundaries
+    (55/56/64, 119/120/128 bytes), thousands of one-character tokens, no tokens at all, multi-byte UTF-8 glued to
+    ASCII, NULs, and batches whose texts differ wildly in length (one wave per claim must not care)."""
+    from lbm_amd import _hip as hip
+    rng = np.random.default_rng(7000 + seed)
+    word = list("abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789_")
+    sep = [" ", "-", ".", "\n", "\t", "\x00", "é", "日", "😀", " ", ",", "!"]
+    texts = []
+    for _ in range(int(rng.choice([1, 7, 300, 2500]))):
+        shape = rng.integers(0, 6)
+        if shape == 0:    # tokens near the padding boundaries
+            toks = ["".join(rng.choice(word, size=int(rng.choice([1, 54, 55, 56, 57, 63, 64, 65, 118, 119, 120, 121, 127, 128, 129, 300])))) for _ in range(int(rng.integers(1, 6)))]
+            texts.append(str(rng.choice(sep)).join(toks))
+        elif shape == 1:  # many tiny tokens
+            texts.append(" ".join(rng.choice(word, size=int(rng.integers(0, 3000)))))
+        elif shape == 2:  # separators only
+            texts.append("".join(rng.choice(sep, size=int(rng.integers(0, 200)))))
+        elif shape == 3:  # noise
+            texts.append("".join(rng.choice(word + sep, size=int(rng.integers(0, 700)))))
+        elif shape == 4:  # one long token
+            texts.append("".join(rng.choice(word, size=int(rng.integers(1, 9000)))))
+        else:             # repeated token (same hash, accumulated many times)
+            texts.append(" ".join([str(rng.choice(["x", "Hello_World", "42"]))] * int(rng.integers(1, 500))))
+    got = hip.embed_batch(texts)
+    want = orc.embed_batch(texts)
+    assert got.tobytes() == want.tobytes()
