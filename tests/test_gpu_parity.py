@@ -235,10 +235,15 @@ def test_randomised_incremental_ops_vs_oracle(hip, seed, hex_hashes):
             kw = {"top_k": rnd.choice([0, 1, 3, 8, 8, 8, 20, 100])}
             if rnd.random() < 0.4:
                 kw["since_ms"] = rnd.randint(0, 55)
+            if rnd.random() < 0.25:  # the opt-in tag filter (extension) rides on the same mirror
+                kw["tags"] = rnd.sample(tags_pool + ["never"], rnd.randint(1, 2))
             assert g.compile(q, **kw) == og.compile(q, **kw), (step, q, kw)
             hs, sc = g.compile_scored(q, **kw)
             ohs, osc = og.compile_scored(q, **kw)
             assert hs == ohs and hexes(sc) == hexes(osc), (step, q, kw)
+            if n_queries % 9 == 0:  # the batched entry must agree with single queries at every state of the graph
+                qs = [q, rnd.choice(vocab), rnd.choice(vocab) + " " + rnd.choice(vocab), ""]
+                assert g.compile_many(qs, **kw) == [og.compile(x, **kw) for x in qs], (step, qs, kw)
             n_queries += 1
     assert n_queries > 100
 
