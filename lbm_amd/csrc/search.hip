@@ -463,14 +463,15 @@ __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index 
 
 // ------------------------------------------------------------------------------------------------
 // K3: batched queries on the matrix cores.  C[N x Q] = E[N x 64] * Q^T is never materialised: a
-// workgroup of 8 waves walks 32-claim tiles of E (staged once in LDS, double-buffered); wave w owns
-// queries 32w..32w+31 and keeps their 64 dims as MFMA B fragments in 32 VGPRs for the whole launch.
-// Per tile a wave issues 32 v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain), so the fp32
-// error bound of the single-query scan holds and the same margin / exact re-rank apply.  The D
-// fragment puts one QUERY on each lane (col = lane & 31) and 16 claims in its registers, so the
-// running threshold of a query is a per-lane register and the since/tag mask is one 32-bit word per
-// tile.  Candidates go to per-query LDS buffers (64 entries); a buffer above 32 entries is sorted in
-// registers by its wave (bitonic across lanes) and cut at k-th - margin.
+// workgroup of 8 waves walks 64-claim super-tiles of E (converted and staged once in LDS, double-
+// buffered); wave w owns queries 32w..32w+31 and keeps their 64 dims as MFMA B fragments in registers
+// for the whole launch.  The D fragment puts one QUERY on each lane (col = lane & 31) and 16 claims in
+// its registers, so the running threshold of a query is a per-lane register and the since/tag mask is
+// one 32-bit word per tile.  Candidates go to per-query LDS buffers (BQ_CAP entries); a buffer above
+// BQ_TRIG entries is cut at (k-th best - margin) by rank counting (one query) or by per-lane top-k lists
+// (all queries of the wave at once).  Three scan precisions share this machinery: scan_batched_kernel
+// <.., BF16 = false> (exact fp32 products), <.., BF16 = true> (split bf16, three products) and
+// scan_batched_f16_kernel (one fp16 product, the default); the margin is twice the error bound of each.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef LBH_BQ_ABLATE
@@ -483,22 +484,6 @@ constexpr int BQ_TS = 68, BQ_TILE_F = 64 * BQ_TS, BQ_NBUF = 2;
 constexpr int BQ_OVER = 0x40000000;  // bit of a query's counter: its candidate set could not be bounded here
 constexpr int BQ_PERQ = 8192;  // candidate slots per query in HBM (256 workgroups x 32)
 constexpr size_t BQ_LDS = (size_t)BQ_MAXQ * BQ_CAP * 8 + BQ_NBUF * BQ_TILE_F * 4 + BQ_MAXQ * 4 * 2;  // 151,552 B
-
-// sort 64 values (one per lane) descending across the wave
-__device__ __forceinline__ uint64_t wave_sort_desc_reg(uint64_t v, int lane) {
-#pragma unroll
-    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-#pragma unroll
-        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            const uint64_t other = __shfl_xor(v, j2);
-            const bool desc_blk = (lane & k2) == 0;
-            const bool lower = (lane & j2) == 0;
-            const uint64_t mx = v > other ? v : other, mn = v > other ? other : v;
-            v = (lower == desc_blk) ? mx : mn;
-        }
-    }
-    return v;
-}
 
 struct bq_ctx {          // per-wave view of the K3 candidate state (LDS) for the out-of-line slow path
     uint64_t* qbuf;

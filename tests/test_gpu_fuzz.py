@@ -18,6 +18,7 @@ from oracle import lb_oracle as orc
 
 pytestmark = pytest.mark.gpu
 ROUNDS = int(os.environ.get("LBM_FUZZ_ROUNDS", "12"))
+SEED0 = int(os.environ.get("LBM_FUZZ_SEED", "0"))  # campaigns beyond the default seeds
 SIZES = [1, 2, 63, 64, 65, 700, 5000, 40_000] + ([300_000] if os.environ.get("LBM_FUZZ_BIG") else [])
 
 
@@ -47,7 +48,7 @@ def _corpus(rng, n, kind):
 @pytest.mark.parametrize("seed", range(ROUNDS))
 def test_search_paths_vs_oracle(seed):
     from lbm_amd import _hip as hip
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + SEED0 + seed)
     n = int(rng.choice(SIZES))
     kind = str(rng.choice(["text", "clustered", "quantised"]))
     emb, keys = _corpus(rng, n, kind)
@@ -104,7 +105,7 @@ def test_embed_random_bytes_vs_oracle(seed):
     (55/56/64, 119/120/128 bytes), thousands of one-character tokens, no tokens at all, multi-byte UTF-8 glued to
     ASCII, NULs, and batches whose texts differ wildly in length (one wave per claim must not care)."""
     from lbm_amd import _hip as hip
-    rng = np.random.default_rng(7000 + seed)
+    rng = np.random.default_rng(7000 + SEED0 + seed)
     word = list("abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789_")
     sep = [" ", "-", ".", "\n", "\t", "\x00", "é", "日", "😀", " ", ",", "!"]
     texts = []
