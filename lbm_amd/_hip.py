@@ -188,6 +188,15 @@ def device_name() -> str:
     return buf.value.decode()
 
 
+def _since(since_ms) -> int:
+    """since_ms as the C ABI's int64: anything at or below INT64_MIN means "no bound" (LBH_SINCE_NONE); a bound no
+    int64 timestamp can reach is an error here -- callers (ContextGraph._filters, Index.recent) answer it themselves."""
+    v = max(int(since_ms), SINCE_NONE)
+    if v > INT64_MAX:
+        raise ValueError("since_ms exceeds the int64 range of created_ms")
+    return v
+
+
 def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(_vp)
 
@@ -309,6 +318,9 @@ class Index:
     def recent(self, since_ms: int = SINCE_NONE, limit: int = 100, stats: Optional[Stats] = None):
         """Newest-first claim ids with created_ms >= since_ms.  Returns (ids, created_ms, matched)."""
         limit = max(0, min(int(limit), self.size()))
+        since_ms = max(int(since_ms), SINCE_NONE)
+        if since_ms > INT64_MAX:  # no storable timestamp reaches the bound
+            return np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.int64), 0
         ids = np.zeros(max(limit, 1), dtype=np.uint64)
         created = np.zeros(max(limit, 1), dtype=np.int64)
         cnt, matched = _i64(0), _i64(0)
@@ -332,7 +344,7 @@ class Index:
         sc = np.zeros((nq, kk), dtype=np.float64)
         cnt = np.zeros(nq, dtype=np.int64)
         if nq and k:
-            _check(self._L.lbh_index_search(self._h, _ptr(q), nq, kk, int(since_ms), int(tag_mask), _ptr(ids),
+            _check(self._L.lbh_index_search(self._h, _ptr(q), nq, kk, _since(since_ms), int(tag_mask), _ptr(ids),
                                             _ptr(sc), _ptr(cnt), ctypes.byref(stats) if stats is not None else None))
         return ids, sc, cnt
 
@@ -346,7 +358,7 @@ class Index:
         sc = np.zeros(max(kk, 1), dtype=np.float64)
         cnt = _i64(0)
         qv = np.zeros(DIM, dtype=np.float64) if want_qvec else None
-        _check(self._L.lbh_index_search_text(self._h, _ptr(buf), len(b), kk, int(since_ms), int(tag_mask), _ptr(ids),
+        _check(self._L.lbh_index_search_text(self._h, _ptr(buf), len(b), kk, _since(since_ms), int(tag_mask), _ptr(ids),
                                              _ptr(sc), ctypes.byref(cnt), _ptr(qv),
                                              ctypes.byref(stats) if stats is not None else None))
         n = cnt.value
@@ -374,7 +386,7 @@ class Index:
                 buf = self._shard_bufs[k] = (ids, sc, keys, cnt, _ptr(ids), _ptr(sc), _ptr(keys), ctypes.byref(cnt))
             ids, sc, keys, cnt, p_ids, p_sc, p_keys, p_cnt = buf
             # the library clamps k to the number of live claims itself
-            _check(self._L.lbh_index_search_shard(self._h, q.ctypes.data, k, int(since_ms), int(tag_mask), p_ids, p_sc,
+            _check(self._L.lbh_index_search_shard(self._h, q.ctypes.data, k, _since(since_ms), int(tag_mask), p_ids, p_sc,
                                                   p_keys, p_cnt, ctypes.byref(stats) if stats is not None else None))
             n = cnt.value
             return ids[:n].copy(), sc[:n].copy(), keys[:n].copy()

@@ -127,3 +127,51 @@ def test_embed_random_bytes_vs_oracle(seed):
     got = hip.embed_batch(texts)
     want = orc.embed_batch(texts)
     assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("seed", range(max(1, ROUNDS // 2)))
+def test_recent_vs_oracle(seed):
+    """The recency query (N3) at index level: timestamp layouts the threshold seed likes (ascending) and dislikes
+    (descending, random, a handful of distinct values), explicit and default order stamps, retracts, paging."""
+    from lbm_amd import _hip as hip
+    rng = np.random.default_rng(9000 + SEED0 + seed)
+    n = int(rng.choice([1, 2, 64, 65, 300, 5000, 70_000]))
+    layout = int(rng.integers(0, 5))
+    if layout == 0:
+        created = np.sort(rng.integers(0, 10 * n, size=n))
+    elif layout == 1:
+        created = np.sort(rng.integers(0, 10 * n, size=n))[::-1].copy()
+    elif layout == 2:
+        created = rng.integers(-2 ** 62, 2 ** 62, size=n)
+    elif layout == 3:
+        created = rng.integers(0, 4, size=n)
+    else:
+        created = np.full(n, int(rng.integers(-5, 5)))
+    created = created.astype(np.int64)
+    if rng.random() < 0.2:
+        created[int(rng.integers(0, n))] = np.iinfo(np.int64).max
+        created[int(rng.integers(0, n))] = np.iinfo(np.int64).min + 1
+    ix = hip.Index()
+    ids = ix.add_vectors(rng.standard_normal((n, 64)), created, np.zeros(n, dtype=np.uint64),
+                         rng.integers(0, 256, size=(n, 32), dtype=np.uint8))
+    order = np.arange(n, dtype=np.uint64)
+    if rng.random() < 0.5:
+        order = rng.permutation(n).astype(np.uint64) + np.uint64(rng.integers(0, 2 ** 40))
+        ix.set_order(ids, order)
+    live = np.ones(n, dtype=bool)
+    if n > 3:
+        dead = rng.choice(n, size=int(n * rng.choice([0.0, 0.1, 0.6])), replace=False)
+        for i in dead.tolist():
+            ix.retract(int(ids[i]))
+        live[dead] = False
+    lidx = np.nonzero(live)[0]
+    for _ in range(6):
+        since = hip.SINCE_NONE if rng.random() < 0.3 else int(rng.choice(created)) + int(rng.integers(-1, 2))
+        since = max(since, hip.SINCE_NONE)
+        limit = int(rng.choice([0, 1, 7, 64, 65, 200, 1000]))
+        got, cr, matched = ix.recent(since, limit)
+        exp = lidx[orc.recent_arrays(created[lidx], order[lidx], since, limit)]
+        assert got.tolist() == ids[exp].tolist(), (seed, n, layout, since, limit)
+        assert cr.tolist() == created[exp].tolist()
+        assert matched == int(np.count_nonzero(created[lidx] >= since))
+    ix.close()
