@@ -954,11 +954,11 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_in
         }
         return (uint32_t)__ballot(rv);
     };
-    auto any_hit = [&](const f32x16& acc) -> bool {
+    auto lane_hit = [&](const f32x16& acc) -> bool {
         bool hit = false;
 #pragma unroll
         for (int r = 0; r < 16; ++r) hit |= acc[r] >= thr_f;
-        return __any(hit);
+        return hit;
     };
     auto harvest = [&](const f32x16& acc, int64_t row0, uint32_t rowmask) {
         thr = bq_harvest_impl<true>(bc, acc, row0, rowmask, thr);
@@ -990,7 +990,6 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_in
         ny1 = load_half(st + 3 * G, 1);
         if (wave_active) {
             const int64_t row0 = row_begin + st * 64;
-            const uint32_t m0 = row_mask(row0), m1 = row_mask(row0 + 32);
             f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             f32x16 acc1 = acc0;
 #pragma unroll
@@ -998,10 +997,16 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_in
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[s], bq[s], acc1, 0, 0, 0);
 #if LBH_BQ_ABLATE >= 2  // timing-only builds: no epilogue
-            asm volatile("" ::"v"(acc0), "v"(acc1), "s"(m0), "s"(m1));
+            asm volatile("" ::"v"(acc0), "v"(acc1));
 #else
-            if (any_hit(acc0)) harvest(acc0, row0, m0);
-            if (any_hit(acc1)) harvest(acc1, row0 + 32, m1);
+            // one wave-wide test for both tiles; the row masks are only built for a tile that has a candidate
+            // (without filters and inside the matrix they are all ones)
+            const bool h0 = lane_hit(acc0), h1 = lane_hit(acc1);
+            if (__any(h0 | h1)) {
+                const bool plain = !SINCE && !TAGS && row0 + 64 <= n;
+                if (__any(h0)) harvest(acc0, row0, plain ? 0xFFFFFFFFu : row_mask(row0));
+                if (__any(h1)) harvest(acc1, row0 + 32, plain ? 0xFFFFFFFFu : row_mask(row0 + 32));
+            }
 #endif
         }
         __syncthreads();
