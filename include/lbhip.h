@@ -69,9 +69,14 @@ int lbh_version(void);
 /* Name of the device the context runs on, e.g. "gfx950:sramecc+:xnack-". */
 int lbh_device_name(lbh_ctx* ctx, char* buf, int buflen);
 
-/* Tuning knobs (no reference counterpart).  name: "scan_blocks_per_cu" (1..8, default 4),
- * "scan_nt" (0/1: non-temporal loads in the fp32 scan).  Also read from the environment at
- * lbh_init as LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT. */
+/* Tuning knobs (no reference counterpart).  name: "scan_blocks_per_cu" (1..8, default 2),
+ * "scan_nt" (0/1: non-temporal loads in the single-query scan), "scan_mode" (0 = scan the fp32
+ * matrix, 256 B/claim, default; 1 = scan a 128 B/claim fp16 copy that the index builds on first
+ * use, wider candidate margin, unit-scale data only - results are the same either way, the
+ * re-rank is always exact fp64), "bq_mode" (batched scan precision: 0 fp32 MFMA, 1 split bf16,
+ * 2 fp16 = default), "spin_us" (completion-ticket polling budget).  Also read from the
+ * environment at lbh_init as LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT / LBH_SCAN_MODE /
+ * LBH_BQ_MODE / LBH_SPIN_US. */
 int lbh_set_option(lbh_ctx* ctx, const char* name, int64_t value);
 
 /* ---- lb/latent.py ----------------------------------------------------------- */

@@ -46,6 +46,7 @@ struct lbh_ctx {
     std::string arch;
     int scan_blocks_per_cu = 2;  // tuning knobs (env LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT), see DESIGN.md
     int scan_nt = 1;
+    int scan_mode = 0;   // single-query scan: 0 = fp32 matrix (256 B/claim), 1 = fp16 copy (128 B/claim, margin 2.2e-3; opt-in)
     int bq_mode = 2;     // batched scan: 0 = exact fp32 MFMA, 1 = split-bf16 products (3 MFMAs at 16x the fp32 rate),
                          // 2 = one fp16 product (a third of the matrix work, margin 2.2e-3)
     int spin_us = 5000;  // poll the completion ticket this long before blocking in hipStreamSynchronize (0 = always block)
@@ -69,6 +70,8 @@ struct lbh_index {
     uint64_t* tags = nullptr;
     uint64_t* keys = nullptr;
     uint64_t* order = nullptr;    // per-row insertion-order key of the recency query (defaults to the claim id)
+    uint16_t* emb16 = nullptr;    // n x 64 fp16 (128 B rows), built on first use of scan_mode 1; rows [0, emb16_rows) are valid
+    int64_t emb16_rows = 0, emb16_cap = 0;
     std::vector<uint64_t> id_of_row;
     std::vector<int64_t> row_of_id;
     lbh_workspace ws{};
@@ -133,6 +136,11 @@ int index_reserve_locked(lbh_index* ix, int64_t want) {
     if ((rc = grow_array(ix->tags, ix->n, want, 1, s))) return rc;
     if ((rc = grow_array(ix->keys, ix->n, want, 4, s))) return rc;
     if ((rc = grow_array(ix->order, ix->n, want, 1, s))) return rc;
+    if (ix->emb16) {  // rebuilt lazily at the next fp16 scan
+        (void)hipFree(ix->emb16);
+        ix->emb16 = nullptr;
+        ix->emb16_rows = ix->emb16_cap = 0;
+    }
     ix->cap = want;
     return LBH_OK;
 }
@@ -199,6 +207,24 @@ hipError_t wait_ticket(lbh_ctx* c, const int32_t* ticket, int32_t seq) {
     return hipStreamSynchronize(c->stream);
 }
 
+// fp16 copy for scan_mode 1: allocate with the index capacity, convert the rows that are not in it yet
+int ensure_emb16(lbh_index* ix) {
+    hipStream_t s = ix->ctx->stream;
+    if (!ix->emb16 || ix->emb16_cap < ix->cap) {
+        if (ix->emb16) (void)hipFree(ix->emb16);
+        ix->emb16 = nullptr;
+        ix->emb16_rows = ix->emb16_cap = 0;
+        HIP_TRY(hipMalloc((void**)&ix->emb16, (size_t)ix->cap * 128));
+        ix->emb16_cap = ix->cap;
+    }
+    if (ix->emb16_rows < ix->n) {
+        HIP_TRY(lbh_launch_f64_to_f16(ix->emb64 + ix->emb16_rows * 64, ix->emb16 + ix->emb16_rows * 64,
+                                      (ix->n - ix->emb16_rows) * 64, s));
+        ix->emb16_rows = ix->n;
+    }
+    return LBH_OK;
+}
+
 struct PageOut {
     int count = 0;
     uint32_t rows[LBH_MAX_PAGE];
@@ -226,9 +252,16 @@ int run_page(lbh_index* ix, int page, int64_t since_ms, uint64_t tag_mask, bool 
     for (;;) {
         hipEvent_t e0 = timing ? ix->ev[0] : nullptr, e1 = timing ? ix->ev[1] : nullptr;
         const int32_t seq = ix->seq = (ix->seq == INT32_MAX) ? 1 : ix->seq + 1;
+        // the fp16 scan is for unit-scale data (its range and its error bound); anything else takes the fp32 matrix
+        const float nscale = norm_scale(ix, ix->qnorm);
+        const bool half = fast && c->scan_mode == 1 && nscale <= 1.001f && nscale >= 0.25f;
+        if (half) {
+            const int rc16 = ensure_emb16(ix);
+            if (rc16) return rc16;
+        }
         if (fast)
-            HIP_TRY(lbh_launch_search_fast(dv, ix->ws, ix->qptr, ix->qarg, page, has_since, since_ms, tag_mask, grid, c->scan_nt, seq,
-                                           LBH_MARGIN * norm_scale(ix, ix->qnorm), s, e0, e1));
+            HIP_TRY(lbh_launch_search_fast(dv, half ? ix->emb16 : nullptr, ix->ws, ix->qptr, ix->qarg, page, has_since, since_ms,
+                                           tag_mask, grid, c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, e0, e1));
         else {
             const int xgrid = std::min(grid, 512);
             HIP_TRY(lbh_launch_search_exact(dv, ix->ws, ix->qptr, ix->qarg, page, has_since, since_ms, tag_mask, cur, xgrid, seq, s, e0, e1));
@@ -244,7 +277,7 @@ int run_page(lbh_index* ix, int page, int64_t since_ms, uint64_t tag_mask, bool 
         }
         if (fast) {
             acc->path = 0;
-            acc->bytes_per_row = 256 + (has_since ? 8 : 0) + (tag_mask ? 8 : 0);
+            acc->bytes_per_row = (half ? 128 : 256) + (has_since ? 8 : 0) + (tag_mask ? 8 : 0);
         } else {
             acc->path = 1;
             acc->bytes_per_row = 512 + (has_since ? 8 : 0) + (tag_mask ? 8 : 0);
@@ -386,6 +419,7 @@ int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx) {
     c->arch = prop.gcnArchName;
     if (const char* e1 = getenv("LBH_SCAN_BLOCKS_PER_CU")) c->scan_blocks_per_cu = std::max(1, std::min(8, atoi(e1)));
     if (const char* e2 = getenv("LBH_SCAN_NT")) c->scan_nt = atoi(e2) != 0;
+    if (const char* e5 = getenv("LBH_SCAN_MODE")) c->scan_mode = atoi(e5) != 0;
     if (const char* e4 = getenv("LBH_BQ_MODE")) c->bq_mode = std::max(0, std::min(2, atoi(e4)));
     if (const char* e3 = getenv("LBH_SPIN_US")) c->spin_us = std::max(0, std::min(1000000, atoi(e3)));
     HIP_TRY(hipSetDevice(c->device));
@@ -417,6 +451,7 @@ int lbh_set_option(lbh_ctx* c, const char* name, int64_t value) {
     std::lock_guard<std::mutex> lk(c->mu);
     if (!strcmp(name, "scan_blocks_per_cu")) c->scan_blocks_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "scan_nt")) c->scan_nt = value != 0;
+    else if (!strcmp(name, "scan_mode")) c->scan_mode = value != 0;
     else if (!strcmp(name, "bq_mode")) c->bq_mode = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else if (!strcmp(name, "spin_us")) c->spin_us = (int)std::max<int64_t>(0, std::min<int64_t>(1000000, value));
     else return fail(LBH_E_INVALID, "unknown option %s", name);
@@ -518,7 +553,7 @@ int lbh_index_destroy(lbh_index* ix) {
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
     lbh_workspace& w = ix->ws;
-    void* dev[] = {ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, ix->order, w.rc_a, w.rc_b, w.rc_row, w.rc_cnt, w.q64, w.cand, w.xcand_ord, w.xcand_row,
+    void* dev[] = {ix->emb16, ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, ix->order, w.rc_a, w.rc_b, w.rc_row, w.rc_cnt, w.q64, w.cand, w.xcand_ord, w.xcand_row,
                    w.flags, w.bq_qmat, w.bq_cand, w.bq_total, w.bq_seed};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -618,13 +653,15 @@ int lbh_index_retract(lbh_index* ix, uint64_t id) {
     HIP_TRY(hipSetDevice(ix->ctx->device));
     const int64_t r = ix->row_of_id[(size_t)id], last = ix->n - 1;
     if (r != last) {
-        HIP_TRY(lbh_launch_move_row(ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, ix->order, r, last, ix->ctx->stream));
+        HIP_TRY(lbh_launch_move_row(ix->emb32, ix->emb64, (ix->emb16 && ix->emb16_rows == ix->n) ? ix->emb16 : nullptr, ix->created, ix->tags, ix->keys, ix->order, r, last, ix->ctx->stream));
         const uint64_t moved = ix->id_of_row[(size_t)last];
         ix->id_of_row[(size_t)r] = moved;
         ix->row_of_id[(size_t)moved] = r;
     }
     ix->row_of_id[(size_t)id] = -1;
     ix->id_of_row.pop_back();
+    if (ix->emb16_rows == ix->n) ix->emb16_rows = ix->n - 1;  // the copy followed the swap-delete
+    else ix->emb16_rows = 0;                                   // rows were pending conversion: rebuild at next use
     ix->n -= 1;
     return LBH_OK;
 }

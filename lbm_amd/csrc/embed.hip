@@ -193,11 +193,18 @@ __global__ void f64_to_f32_kernel(const double* __restrict__ in, float* __restri
         out[i] = (float)in[i];
 }
 
+// fp16 copy of the matrix for the opt-in fp16 scan: round to nearest even (the scan's error bound assumes it)
+__global__ void f64_to_f16_kernel(const double* __restrict__ in, _Float16* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (_Float16)(float)in[i];
+}
+
 // swap-delete support: copy row `src` over row `dst` in every per-claim array
-__global__ void move_row_kernel(float* emb32, double* emb64, int64_t* created, uint64_t* tags, uint64_t* keys,
+__global__ void move_row_kernel(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
                                 uint64_t* order, int64_t dst, int64_t src) {
     const int l = threadIdx.x;
     emb32[dst * 64 + l] = emb32[src * 64 + l];
+    if (emb16) emb16[dst * 64 + l] = emb16[src * 64 + l];
     emb64[dst * 64 + l] = emb64[src * 64 + l];
     if (l < 4) keys[dst * 4 + l] = keys[src * 4 + l];
     if (l == 4) created[dst] = created[src];
@@ -241,9 +248,17 @@ hipError_t lbh_launch_f64_to_f32(const double* in_dev, float* out_dev, int64_t n
     return hipGetLastError();
 }
 
-hipError_t lbh_launch_move_row(float* emb32, double* emb64, int64_t* created, uint64_t* tags, uint64_t* keys,
+hipError_t lbh_launch_move_row(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
                                uint64_t* order, int64_t dst, int64_t src, hipStream_t s) {
-    move_row_kernel<<<1, 64, 0, s>>>(emb32, emb64, created, tags, keys, order, dst, src);
+    move_row_kernel<<<1, 64, 0, s>>>(emb32, emb64, emb16, created, tags, keys, order, dst, src);
+    return hipGetLastError();
+}
+
+hipError_t lbh_launch_f64_to_f16(const double* in_dev, uint16_t* out_dev, int64_t n_elems, hipStream_t s) {
+    if (n_elems <= 0) return hipSuccess;
+    int64_t blocks = (n_elems + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    f64_to_f16_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(in_dev, reinterpret_cast<_Float16*>(out_dev), n_elems);
     return hipGetLastError();
 }
 

@@ -131,13 +131,15 @@ hipError_t lbh_launch_embed(const uint8_t* utf8_dev, const int64_t* offsets_dev,
                             float* out32_dev, hipStream_t s);
 hipError_t lbh_launch_cosine(const double* a_dev, const double* b_dev, int64_t n, double* out_dev, hipStream_t s);
 hipError_t lbh_launch_f64_to_f32(const double* in_dev, float* out_dev, int64_t n_elems, hipStream_t s);
-hipError_t lbh_launch_move_row(float* emb32, double* emb64, int64_t* created, uint64_t* tags, uint64_t* keys,
+hipError_t lbh_launch_move_row(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
                                uint64_t* order, int64_t dst, int64_t src, hipStream_t s);
+hipError_t lbh_launch_f64_to_f16(const double* in_dev, uint16_t* out_dev, int64_t n_elems, hipStream_t s);
 hipError_t lbh_launch_iota_u64(uint64_t* dst, uint64_t first, int64_t n, hipStream_t s);
 hipError_t lbh_launch_scatter_u64(uint64_t* dst, const int64_t* rows_dev, const uint64_t* vals_dev, int64_t n, hipStream_t s);
 // search.hip
 int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu);
-hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
+// emb16: NULL = scan the fp32 matrix; else the fp16 copy (opt-in scan_mode 1; `margin` must then be the fp16 one)
+hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, const double* qptr,
                                   const lbh_qarg& qa, int k, int has_since,
                                   int64_t since_ms, uint64_t tag_mask, int grid, int nt, int seq, float margin,
                                   hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);

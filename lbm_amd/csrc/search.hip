@@ -117,8 +117,16 @@ __device__ __forceinline__ double exact_dot(const double* __restrict__ q, const 
 // leaving lane (g, c) with the complete score of tile row 4c + g.  Every row goes through the same
 // reduction tree, so bit-identical rows get bit-identical scores wherever they sit.
 // ------------------------------------------------------------------------------------------------
-template <bool SINCE, bool TAGS, bool NT>
-__global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_index ix, const double* __restrict__ qptr, lbh_qarg qa,
+//
+// HALF = true is the opt-in fp16 flavour (`scan_mode` 1): it streams a 128 B/claim fp16 copy of the matrix instead
+// (lane l, load j: halves [8c, 8c+8) of tile row 8j + g, c = l & 7, g = l >> 3; three butterfly steps), scores with
+// fp32 FMAs of the (exact) fp16 products and cuts with the fp16 margin (LBH_MARGIN_F16, see scan_batched_f16_kernel for the bound).  The
+// exact re-rank makes the result identical; only the bytes per claim change.
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+
+template <bool SINCE, bool TAGS, bool NT, bool HALF>
+__global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_index ix, const uint16_t* __restrict__ emb16,
+                                                                     const double* __restrict__ qptr, lbh_qarg qa,
                                                                      int k, float margin, int64_t since_ms, uint64_t tag_mask,
                                                                      uint64_t* __restrict__ cand,
                                                                      int32_t* __restrict__ flags) {
@@ -128,15 +136,22 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
+    const int c = HALF ? (lane & 7) : (lane & 15), g = HALF ? (lane >> 3) : (lane >> 4);
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     // query: device pointer (search_text: embedded on the GPU) or the kernel-argument copy (no H2D copy)
     const double* __restrict__ qd = qptr ? qptr : qa.q;
-    const f32x4 qf = {(float)qd[4 * c], (float)qd[4 * c + 1], (float)qd[4 * c + 2], (float)qd[4 * c + 3]};
+    const f32x4 qf = {(float)qd[4 * (c & 15)], (float)qd[4 * (c & 15) + 1], (float)qd[4 * (c & 15) + 2], (float)qd[4 * (c & 15) + 3]};
+    h2_t qh[4];  // HALF: this lane's 8 query dims as packed fp16 (round to nearest even)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        qh[e].x = (_Float16)(float)qd[8 * (c & 7) + 2 * e];
+        qh[e].y = (_Float16)(float)qd[8 * (c & 7) + 2 * e + 1];
+    }
     const f32x4* __restrict__ E = reinterpret_cast<const f32x4*>(ix.emb32);
+    const f32x4* __restrict__ E16 = reinterpret_cast<const f32x4*>(emb16);
     const int64_t n = ix.n;
     const int64_t n_tiles = (n + 63) >> 6;
-    const int64_t n_vec = n * 16;
+    const int64_t n_vec = n * (HALF ? 8 : 16);  // 16-byte chunks in the scanned matrix
     uint64_t* buf = wbuf[wave];
 
     uint32_t thr = 0;  // ordered image of (k-th best so far - margin); 0 admits everything
@@ -169,44 +184,85 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
 
     for (int64_t tile = (int64_t)blockIdx.x * LBH_SCAN_WAVES + wave; tile < n_tiles && !dead;
          tile += (int64_t)gridDim.x * LBH_SCAN_WAVES) {
-        const int64_t v0 = tile * 1024 + lane;
-        f32x4 x[16];
-        if (v0 + 1024 - lane <= n_vec) {
+        float s;
+        int64_t myrow;
+        if (!HALF) {
+            const int64_t v0 = tile * 1024 + lane;
+            f32x4 x[16];
+            if (v0 + 1024 - lane <= n_vec) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) x[j] = NT ? __builtin_nontemporal_load(&E[v0 + j * 64]) : E[v0 + j * 64];
+                for (int j = 0; j < 16; ++j) x[j] = NT ? __builtin_nontemporal_load(&E[v0 + j * 64]) : E[v0 + j * 64];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) x[j] = (v0 + j * 64 < n_vec) ? E[v0 + j * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            myrow = tile * 64 + 4 * c + g;
+            float p[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                p[j] = fmaf(x[j].w, qf.w, fmaf(x[j].z, qf.z, fmaf(x[j].y, qf.y, x[j].x * qf.x)));
+            // butterfly: after the step with mask m a lane keeps the rows whose bit matches its own
+            float r8[8], r4[4], r2[2];
+            const bool b8 = c & 8, b4 = c & 4, b2 = c & 2, b1 = c & 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float keep = b8 ? p[j + 8] : p[j], send = b8 ? p[j] : p[j + 8];
+                r8[j] = keep + __shfl_xor(send, 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float keep = b4 ? r8[j + 4] : r8[j], send = b4 ? r8[j] : r8[j + 4];
+                r4[j] = keep + __shfl_xor(send, 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float keep = b2 ? r4[j + 2] : r4[j], send = b2 ? r4[j] : r4[j + 2];
+                r2[j] = keep + __shfl_xor(send, 2);
+            }
+            const float keep1 = b1 ? r2[1] : r2[0], send1 = b1 ? r2[0] : r2[1];
+            s = keep1 + __shfl_xor(send1, 1);
         } else {
+            const int64_t v0 = tile * 512 + lane;
+            f32x4 x[8];  // 16 raw bytes = 8 halves per load (typed as floats only to reuse the 128-bit load path)
+            if (v0 + 512 - lane <= n_vec) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) x[j] = (v0 + j * 64 < n_vec) ? E[v0 + j * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 8; ++j) x[j] = NT ? __builtin_nontemporal_load(&E16[v0 + j * 64]) : E16[v0 + j * 64];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = (v0 + j * 64 < n_vec) ? E16[v0 + j * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            myrow = tile * 64 + 8 * c + g;
+            float p[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a = 0.f;  // fp16 x fp16 products are exact in fp32; eight fp32 accumulations per chunk
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xw = e == 0 ? x[j].x : e == 1 ? x[j].y : e == 2 ? x[j].z : x[j].w;
+                    const h2_t xe = __builtin_bit_cast(h2_t, xw);
+                    a = fmaf((float)xe.x, (float)qh[e].x, a);
+                    a = fmaf((float)xe.y, (float)qh[e].y, a);
+                }
+                p[j] = a;
+            }
+            float r4[4], r2[2];
+            const bool b4 = c & 4, b2 = c & 2, b1 = c & 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float keep = b4 ? p[j + 4] : p[j], send = b4 ? p[j] : p[j + 4];
+                r4[j] = keep + __shfl_xor(send, 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float keep = b2 ? r4[j + 2] : r4[j], send = b2 ? r4[j] : r4[j + 2];
+                r2[j] = keep + __shfl_xor(send, 2);
+            }
+            const float keep1 = b1 ? r2[1] : r2[0], send1 = b1 ? r2[0] : r2[1];
+            s = keep1 + __shfl_xor(send1, 1);
         }
-        const int64_t myrow = tile * 64 + 4 * c + g;
         bool valid = myrow < n;
         if (SINCE) valid = valid && (ix.created[valid ? myrow : 0] >= since_ms);
         if (TAGS) valid = valid && ((ix.tags[myrow < n ? myrow : 0] & tag_mask) != 0);
-
-        float p[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            p[j] = fmaf(x[j].w, qf.w, fmaf(x[j].z, qf.z, fmaf(x[j].y, qf.y, x[j].x * qf.x)));
-        // butterfly: after the step with mask m a lane keeps the rows whose bit matches its own
-        float r8[8], r4[4], r2[2];
-        const bool b8 = c & 8, b4 = c & 4, b2 = c & 2, b1 = c & 1;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float keep = b8 ? p[j + 8] : p[j], send = b8 ? p[j] : p[j + 8];
-            r8[j] = keep + __shfl_xor(send, 8);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float keep = b4 ? r8[j + 4] : r8[j], send = b4 ? r8[j] : r8[j + 4];
-            r4[j] = keep + __shfl_xor(send, 4);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float keep = b2 ? r4[j + 2] : r4[j], send = b2 ? r4[j] : r4[j + 2];
-            r2[j] = keep + __shfl_xor(send, 2);
-        }
-        const float keep1 = b1 ? r2[1] : r2[0], send1 = b1 ? r2[0] : r2[1];
-        const float s = keep1 + __shfl_xor(send1, 1);
 
         const uint32_t o = lbh_ord32(s);
         const bool pass = valid && o >= thr;
@@ -1566,25 +1622,29 @@ int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu) {
     return (int)blocks;
 }
 
-hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
+hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, const double* qptr,
                                   const lbh_qarg& qa, int k, int has_since,
                                   int64_t since_ms, uint64_t tag_mask, int grid, int nt, int seq, float margin,
                                   hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     hipError_t e;
     if (ev0) (void)hipEventRecord(ev0, s);
     const dim3 g(grid), b(LBH_SCAN_THREADS);
-#define LBH_SCAN_ARGS ix, qptr, qa, k, margin, since_ms, tag_mask, ws.cand, ws.flags
-    if (nt) {
-        if (has_since && tag_mask) scan_f32_kernel<true, true, true><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
-        else if (has_since) scan_f32_kernel<true, false, true><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
-        else if (tag_mask) scan_f32_kernel<false, true, true><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
-        else scan_f32_kernel<false, false, true><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
+#define LBH_SCAN_ARGS ix, emb16, qptr, qa, k, margin, since_ms, tag_mask, ws.cand, ws.flags
+#define LBH_SCAN_DISPATCH(NTV, HV)                                                                           \
+    do {                                                                                                     \
+        if (has_since && tag_mask) scan_f32_kernel<true, true, NTV, HV><<<g, b, 0, s>>>(LBH_SCAN_ARGS);      \
+        else if (has_since) scan_f32_kernel<true, false, NTV, HV><<<g, b, 0, s>>>(LBH_SCAN_ARGS);            \
+        else if (tag_mask) scan_f32_kernel<false, true, NTV, HV><<<g, b, 0, s>>>(LBH_SCAN_ARGS);             \
+        else scan_f32_kernel<false, false, NTV, HV><<<g, b, 0, s>>>(LBH_SCAN_ARGS);                          \
+    } while (0)
+    if (emb16) {
+        if (nt) LBH_SCAN_DISPATCH(true, true);
+        else LBH_SCAN_DISPATCH(false, true);
     } else {
-        if (has_since && tag_mask) scan_f32_kernel<true, true, false><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
-        else if (has_since) scan_f32_kernel<true, false, false><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
-        else if (tag_mask) scan_f32_kernel<false, true, false><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
-        else scan_f32_kernel<false, false, false><<<g, b, 0, s>>>(LBH_SCAN_ARGS);
+        if (nt) LBH_SCAN_DISPATCH(true, false);
+        else LBH_SCAN_DISPATCH(false, false);
     }
+#undef LBH_SCAN_DISPATCH
 #undef LBH_SCAN_ARGS
     if (ev1) (void)hipEventRecord(ev1, s);
     e = hipGetLastError();

@@ -80,12 +80,15 @@ def test_search_paths_vs_oracle(seed):
     tmask = 0 if rng.random() < 0.6 else int(rng.integers(1, 256))
     want = [orc.compile_arrays(emb, created, retr, None, q[j], k, since, tagmask, tmask, packed_keys=packed) for j in range(nq)]
     st = hip.Stats()
-    for j in range(nq):  # single-query path (fast scan, exact fallback, paging)
-        gi, gs, _ = ix.search_shard(q[j], k, hip.SINCE_NONE if since is None else since, tmask, st)
-        assert ids[want[j][0]].tolist() == gi.tolist(), ("single", seed, j, kind, n, k, since, tmask)
-        assert want[j][1].tobytes() == gs.tobytes(), ("single", seed, j)
-        if st.path == 0 and unit:
-            assert st.max_score_err < 5e-6
+    for smode in (0, 1):  # single-query path (fast scan over the fp32 matrix or the fp16 copy, exact fallback, paging)
+        hip.set_option("scan_mode", smode)
+        for j in range(nq):
+            gi, gs, _ = ix.search_shard(q[j], k, hip.SINCE_NONE if since is None else since, tmask, st)
+            assert ids[want[j][0]].tolist() == gi.tolist(), ("single", smode, seed, j, kind, n, k, since, tmask)
+            assert want[j][1].tobytes() == gs.tobytes(), ("single", smode, seed, j)
+            if st.path == 0 and unit:
+                assert st.max_score_err < (1.1e-3 if smode else 5e-6)
+    hip.set_option("scan_mode", 0)
     for mode, margin in ((2, 2.2e-3), (1, 1e-4), (0, 1e-5)):  # batched path in each scan precision
         hip.set_option("bq_mode", mode)
         gi, gs, cnt = ix.search(q, k, hip.SINCE_NONE if since is None else since, tmask, st)

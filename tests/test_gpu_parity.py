@@ -170,8 +170,8 @@ def test_cache_view_and_direct_mutation_semantics(hip):
     assert g.compile("changed") == og.compile("changed") == ("Context slice\nQuery: changed\n", [])
 
 
-@pytest.mark.parametrize("seed,hex_hashes", [(11, True), (12, False), (13, True)])
-def test_randomised_incremental_ops_vs_oracle(hip, seed, hex_hashes):
+@pytest.mark.parametrize("seed,hex_hashes,smode", [(11, True, 0), (12, False, 0), (13, True, 0), (14, True, 1), (15, False, 1)])
+def test_randomised_incremental_ops_vs_oracle(hip, seed, hex_hashes, smode):
     """publish / overwrite / retract / direct edits interleaved with queries.  The device
     mirror is updated incrementally (appends, swap-deletes, metadata pokes); after every mutation burst the
     ranking, scores and context text must equal the reference semantics (oracle graph, pinned by golden)."""
@@ -179,6 +179,7 @@ def test_randomised_incremental_ops_vs_oracle(hip, seed, hex_hashes):
     import random
     from lbm_amd.context_graph import ContextGraph
     rnd = random.Random(seed)
+    hip.set_option("scan_mode", smode)  # 1: the fp16 copy has to follow appends, swap-deletes and regrowth
     vocab = ["alpha", "beta", "gamma", "delta", "eps", "zeta", "eta", "theta", "iota", "kappa", "lam", "mu",
              "nu", "xi", "omi", "pi", "rho", "sigma", "tau", "ups", "phi", "chi", "psi", "omega", "x1", "y_2"]
     tags_pool = ["a", "b", "c", "d"]
@@ -245,6 +246,7 @@ def test_randomised_incremental_ops_vs_oracle(hip, seed, hex_hashes):
                 qs = [q, rnd.choice(vocab), rnd.choice(vocab) + " " + rnd.choice(vocab), ""]
                 assert g.compile_many(qs, **kw) == [og.compile(x, **kw) for x in qs], (step, qs, kw)
             n_queries += 1
+    hip.set_option("scan_mode", 0)
     assert n_queries > 100
 
 
@@ -307,7 +309,16 @@ def _arrays_case(n, seed, dup_frac=0.002):
     return ch
 
 
-def test_index_vs_oracle_200k(hip):
+@pytest.fixture(params=["scan_fp32", "scan_fp16"])
+def scan_mode(request, hip):
+    """Single-query scan over the fp32 matrix (default) or over the opt-in fp16 copy; results must not differ."""
+    mode = 1 if request.param == "scan_fp16" else 0
+    hip.set_option("scan_mode", mode)
+    yield mode
+    hip.set_option("scan_mode", 0)
+
+
+def test_index_vs_oracle_200k(hip, scan_mode):
     """C-ABI level: 200k synthetic claims, fast path / paging / filters / tag mask, all bit-exact."""
     from lbm_amd import synth
     ch = _arrays_case(200_000, 77)
@@ -342,6 +353,8 @@ def test_index_vs_oracle_200k(hip):
                 assert st.fallbacks >= 1 and st.path == 1  # all scores 0.0: pure hash order via the exact path
             elif k <= 64:
                 assert st.path == 0 and st.fallbacks == 0 and st.candidates >= n
+                assert st.bytes_per_row == (128 if scan_mode else 256) + (8 if since is not None else 0) + (8 if tmask else 0)
+                assert st.max_score_err < (1.1e-3 if scan_mode else 5e-6)
     # text entry point == vector entry point
     gi, gs, _ = ix.search_text(queries[0], 8)
     gi2, gs2, _ = ix.search(orc.embed_array(queries[0])[None, :], 8)

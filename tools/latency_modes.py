@@ -45,6 +45,10 @@ def main():
             _hip.set_option("spin_us", spin)
             for timing in (0, 1, 2):
                 res[f"spin_us={spin},timing={timing}"] = measure(ix, qv, 8, timing)
+        _hip.set_option("scan_mode", 1)  # opt-in: scan a 128 B/claim fp16 copy, re-rank in fp64 as always
+        for timing in (0, 1):
+            res[f"scan_mode=1,spin_us=5000,timing={timing}"] = measure(ix, qv, 8, timing)
+        _hip.set_option("scan_mode", 0)
         out[str(n)] = res
         ix.close()
     print(json.dumps(out, indent=1))
