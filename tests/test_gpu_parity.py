@@ -303,6 +303,75 @@ def test_queries_overlap_publishes_from_another_thread(hip):
     assert g.recent(1000, 50) == [c["claim_hash"] for c in orc.recent_claims(og.claims, 1000, 50)]
 
 
+def test_c_abi_calls_from_many_threads(hip):
+    """The library's own locking (per-index mutex, per-context scratch mutex), without the Python graph lock in
+    front of it: four threads search two indexes (single-query, batched, recency, text embedding) while a fifth
+    appends to and retracts from a third index on the same context.  Every answer must equal the one computed
+    before the threads started."""
+    import threading
+    rng = np.random.default_rng(5)
+
+    def make(n):
+        v = rng.standard_normal((n, 64))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        ix = hip.Index()
+        ids = ix.add_vectors(v, rng.integers(0, 1000, size=n).astype(np.int64), None, rng.integers(0, 256, size=(n, 32), dtype=np.uint8))
+        return ix, ids
+
+    (a, _), (b, _), (c, _) = make(30_000), make(4_000), make(100)
+    qs = rng.standard_normal((8, 64))
+    qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+    texts = ["alpha beta %d" % i for i in range(50)]
+    want = {}
+    for name, ix in (("a", a), ("b", b)):
+        want[name] = ([tuple(x.tobytes() for x in ix.search_shard(qs[j], 8, hip.SINCE_NONE, 0)) for j in range(8)],
+                      tuple(x.tobytes() for x in ix.search(qs, 8)), tuple(np.asarray(x).tobytes() for x in ix.recent(500, 20)[:2]))
+    want_emb = hip.embed_batch(texts).tobytes()
+    errors, stop = [], threading.Event()
+
+    def reader(seed):
+        try:
+            r = np.random.default_rng(seed)
+            for it in range(150):
+                name, ix = (("a", a), ("b", b))[int(r.integers(0, 2))]
+                what = int(r.integers(0, 4))
+                if what == 0:
+                    j = int(r.integers(0, 8))
+                    assert tuple(x.tobytes() for x in ix.search_shard(qs[j], 8, hip.SINCE_NONE, 0)) == want[name][0][j]
+                elif what == 1:
+                    assert tuple(x.tobytes() for x in ix.search(qs, 8)) == want[name][1]
+                elif what == 2:
+                    assert tuple(np.asarray(x).tobytes() for x in ix.recent(500, 20)[:2]) == want[name][2]
+                else:
+                    assert hip.embed_batch(texts).tobytes() == want_emb
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    def writer():
+        try:
+            r = np.random.default_rng(99)
+            while not stop.is_set():
+                v = r.standard_normal((64, 64))
+                ids = c.add_vectors(v, np.zeros(64, dtype=np.int64), None, r.integers(0, 256, size=(64, 32), dtype=np.uint8))
+                for i in ids[::2].tolist():
+                    c.retract(int(i))
+                c.search_shard(qs[0], 4, hip.SINCE_NONE, 0)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=reader, args=(s,)) for s in range(4)]
+    w = threading.Thread(target=writer)
+    for t in ts + [w]:
+        t.start()
+    for t in ts:
+        t.join(timeout=100)
+    stop.set()
+    w.join(timeout=30)
+    assert not errors, errors
+    for ix in (a, b, c):
+        ix.close()
+
+
 def _arrays_case(n, seed, dup_frac=0.002):
     from lbm_amd import synth
     ch = synth.make_chunk(0, n, seed=seed, real_sha_keys=False, dup_frac=dup_frac)
