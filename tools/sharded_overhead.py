@@ -36,6 +36,22 @@ def main():
             t0 = time.perf_counter(); s.search(qv[i % 64], k, _hip.SINCE_NONE, 0); b.append(time.perf_counter() - t0)
         out[f"k{k}"] = {"local_p50_us": float(np.percentile(a, 50) * 1e6), "sharded_p50_us": float(np.percentile(b, 50) * 1e6),
                         "exchange_overhead_us": float((np.percentile(b, 50) - np.percentile(a, 50)) * 1e6)}
+    # host-side cost of each phase of ShardedSearcher.search (k = 8), same calls in the same order
+    from lbm_amd.sharded import pack_local
+    b = s._bufs[8]
+    ph = {x: [] for x in ("pack", "h2d_launch", "allgather_launch", "d2h_launch", "sync", "merge")}
+    for i in range(300):
+        ids, sc, keys = ix.search_shard(qv[i % 64], 8, _hip.SINCE_NONE, 0)
+        t = [time.perf_counter()]
+        local = pack_local(sc, s.gid_of_local(np.asarray(ids)), keys, 8); b.send_np[...] = local; t.append(time.perf_counter())
+        b.send_dev.copy_(b.send_host, non_blocking=True); t.append(time.perf_counter())
+        dist.all_gather_into_tensor(b.recv_dev, b.send_dev); t.append(time.perf_counter())
+        b.recv_host.copy_(b.recv_dev, non_blocking=True); t.append(time.perf_counter())
+        torch.cuda.current_stream().synchronize(); t.append(time.perf_counter())
+        s._merge(b.recv_np, 8); t.append(time.perf_counter())
+        for j, x in enumerate(ph):
+            ph[x].append(t[j + 1] - t[j])
+    out["phases_p50_us"] = {x: float(np.percentile(v, 50) * 1e6) for x, v in ph.items()}
     print(json.dumps(out, indent=1))
     dist.destroy_process_group()
 
