@@ -85,6 +85,11 @@ def test_fast_vs_exact_vs_batched_10m(corpus):
         assert bi[j, : int(bc[j])].tolist() == i8.tolist() and bs[j, : int(bc[j])].tobytes() == s8.tobytes()
         again, s_again, _ = ix.search_shard(q[j], 8, hip.SINCE_NONE, 0)
         assert again.tolist() == i8.tolist() and s_again.tobytes() == s8.tobytes()  # idempotent
+        hip.set_option("scan_mode", 1)  # the fp16 copy of the matrix as scan operand: same answer, half the bytes
+        h8, hs8, _ = ix.search_shard(q[j], 8, hip.SINCE_NONE, 0, st)
+        hip.set_option("scan_mode", 0)
+        assert st.path == 0 and st.bytes_per_row == 128 and st.max_score_err < 1.1e-3
+        assert h8.tolist() == i8.tolist() and hs8.tobytes() == s8.tobytes()
         if j < 12:
             i64, s64, _ = ix.search_shard(q[j], 64, hip.SINCE_NONE, 0)
             i200, s200, _ = ix.search_shard(q[j], 200, hip.SINCE_NONE, 0, st)  # pages 2.. use the exact path
