@@ -865,14 +865,23 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
         hipStream_t s = c->stream;
         const lbh_dev_index dv = dev_view(ix);
         const int has_since = since_ms != LBH_SINCE_NONE;
+        bool any16 = false;
         for (int64_t q0 = 0; q0 < nq; q0 += LBH_BQ_MAXQ) {
             const int nb = (int)std::min<int64_t>(LBH_BQ_MAXQ, nq - q0);
             double qn = 0.0;
             for (int q = 0; q < nb; ++q) qn = std::max(qn, vec_norm(q_f64 + (q0 + q) * 64));
             if (!(qn <= 1e15)) return fail(LBH_E_INVALID, "a query vector is not finite (or its norm exceeds 1e15)");
             HIP_TRY(hipMemcpyAsync(ix->ws.bq_qmat, q_f64 + q0 * 64, (size_t)nb * 512, hipMemcpyHostToDevice, s));
-            HIP_TRY(lbh_launch_search_batched(dv, ix->ws, nb, (int)keff, has_since, since_ms, tag_mask, c->n_cu, c->bq_mode,
-                                              norm_scale(ix, qn), s,
+            const float nscale = norm_scale(ix, qn);
+            // scan_mode 1 keeps an fp16 copy of the matrix: the fp16 kernel then streams 128 B/claim and skips the conversion
+            const bool src16 = c->scan_mode == 1 && c->bq_mode == 2 && nscale >= 0.25f && nscale <= 1.001f;
+            if (src16) {
+                const int rc16 = ensure_emb16(ix);
+                if (rc16) return rc16;
+            }
+            any16 = any16 || src16;
+            HIP_TRY(lbh_launch_search_batched(dv, src16 ? ix->emb16 : nullptr, ix->ws, nb, (int)keff, has_since, since_ms, tag_mask, c->n_cu, c->bq_mode,
+                                              nscale, s,
                                               timing ? ix->ev[0] : nullptr, timing ? ix->ev[1] : nullptr));
             HIP_TRY(hipStreamSynchronize(s));
             total.scan_launches += 1;
@@ -896,7 +905,7 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
             }
         }
         total.path = 2;
-        total.bytes_per_row = 256 + (has_since ? 8 : 0) + (tag_mask ? 8 : 0);
+        total.bytes_per_row = (any16 ? 128 : 256) + (has_since ? 8 : 0) + (tag_mask ? 8 : 0);
     }
     for (int64_t q = 0; q < nq; ++q) {
         if (done[(size_t)q]) continue;

@@ -150,6 +150,7 @@ hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace&
 hipError_t lbh_launch_recent(const int64_t* created, const uint64_t* order, int64_t n, const lbh_workspace& ws,
                              int page, int has_since, int64_t since_ms, const lbh_rcursor& cur, int64_t anchor_row,
                              int n_cu, int seq, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
-hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspace& ws, int nq, int k, int has_since,
+// emb16: NULL, or the fp16 copy of the matrix as operand source of the fp16 mode (bf16 == 2)
+hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, int nq, int k, int has_since,
                                      int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, float norm_scale, hipStream_t s,
                                      hipEvent_t ev0, hipEvent_t ev1);

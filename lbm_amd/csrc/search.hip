@@ -693,6 +693,44 @@ __device__ __forceinline__ uint32_t bq_harvest_impl(const bq_ctx& c, const f32x1
     }
     return thr;
 }
+// The same slow path for a caller that already knows WHICH lanes hold a candidate (the fp16 kernel's max test):
+// only those lanes walk their 16 scores, everyone else skips the loop, and the buffer fill is taken from the
+// positions the appends returned instead of a second LDS read.  A candidate tile costs the wave about a third of
+// bq_harvest_impl's time -- and the other seven waves of the workgroup wait for it at the tile barrier.
+__device__ __forceinline__ uint32_t bq_harvest_lanes(const bq_ctx& c, const f32x16& acc, int64_t row0, uint32_t rowmask,
+                                                     uint32_t thr, bool lanehit) {
+    int last = -1;  // highest buffer position this lane took
+    if (lanehit && c.qactive) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rowbit = (r & 3) + 8 * (r >> 2) + 4 * c.h;
+            const uint32_t o = lbh_ord32(acc[r]);
+            if (((rowmask >> rowbit) & 1u) && o >= thr) {
+                const int pos = atomicAdd(&c.qcnt[c.myq], 1);
+                if (pos < BQ_CAP) c.qbuf[(size_t)c.myq * BQ_CAP + pos] = ((uint64_t)o << 32) | (uint32_t)(row0 + rowbit);
+                else atomicOr(&c.qtotal[c.myq], BQ_OVER);
+                last = pos;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint64_t need = __ballot(last >= BQ_TRIG);  // the query's count passed the trigger with this tile
+    need = (need | (need >> 32)) & 0xFFFFFFFFull;  // lanes L and L + 32 serve the same query
+    if (need) {
+        if (__popcll(need) > 2) {
+            bq_compact_all(c, need);
+        } else {
+            uint64_t rest = need;
+            while (rest) {
+                const int qi = __ffsll((long long)rest) - 1;
+                rest &= rest - 1;
+                bq_compact_impl(c, c.wave * 32 + qi);
+            }
+        }
+        if (c.qactive) thr = c.qthr[c.myq];
+    }
+    return thr;
+}
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -948,8 +986,9 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <bool SINCE, bool TAGS>
-__global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_index ix, const double* __restrict__ qmat,
+template <bool SINCE, bool TAGS, bool SRC16>
+__global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_index ix, const uint16_t* __restrict__ emb16,
+                                                                       const double* __restrict__ qmat,
                                                                        int nq, int k, float margin, int64_t since_ms, uint64_t tag_mask,
                                                                        int64_t row_begin, int64_t row_end,
                                                                        const uint32_t* __restrict__ seed,
@@ -996,6 +1035,19 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_in
         char* d = reinterpret_cast<char*>(tile + (size_t)buf * BQ_TILE_F + (half * 32 + srow) * BQ_TS) + 8 * sc4;
         *reinterpret_cast<f16x4*>(d) = __builtin_convertvector(v, f16x4);
     };
+    // SRC16: the index keeps an fp16 copy of the matrix (scan_mode 1): a super-tile is 8 KiB, one 16-byte load and
+    // one ds_write_b128 per thread, no conversion
+    const f32x4* __restrict__ E16 = reinterpret_cast<const f32x4*>(emb16);
+    const int srow16 = tid >> 3, sc8 = tid & 7;
+    auto load16 = [&](int64_t sti) -> f32x4 {
+        int64_t r = row_begin + sti * 64 + srow16;
+        r = r < n ? r : n - 1;
+        return __builtin_nontemporal_load(&E16[r * 8 + sc8]);
+    };
+    auto store16 = [&](int buf, f32x4 v) {
+        char* d = reinterpret_cast<char*>(tile + (size_t)buf * BQ_TILE_F + srow16 * BQ_TS) + 16 * sc8;
+        *reinterpret_cast<f32x4*>(d) = v;
+    };
     bq_ctx bc;
     bc.qbuf = qbuf; bc.qcnt = qcnt; bc.qthr = qthr; bc.qtotal = qtotal;
     bc.k = k; bc.lane = lane; bc.wave = wave; bc.myq = myq; bc.h = h; bc.qactive = qactive;
@@ -1010,14 +1062,15 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_in
         }
         return (uint32_t)__ballot(rv);
     };
-    auto lane_hit = [&](const f32x16& acc) -> bool {
-        bool hit = false;
+    auto lane_hit = [&](const f32x16& acc) -> bool {  // max of the 16 scores (8 v_max3_f32), one compare
+        float m = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hit |= acc[r] >= thr_f;
-        return hit;
+        for (int r = 3; r < 15; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, acc[r]), acc[r + 1]);
+        m = __builtin_fmaxf(m, acc[15]);
+        return m >= thr_f;
     };
-    auto harvest = [&](const f32x16& acc, int64_t row0, uint32_t rowmask) {
-        thr = bq_harvest_impl<true>(bc, acc, row0, rowmask, thr);
+    auto harvest = [&](const f32x16& acc, int64_t row0, uint32_t rowmask, bool lanehit) {
+        thr = bq_harvest_lanes(bc, acc, row0, rowmask, thr, lanehit);
         if (qactive) thr_f = thr ? lbh_unord32(thr) : -__builtin_inff();
     };
 
@@ -1031,19 +1084,34 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_in
         for (int s = 0; s < 4; ++s) a1[s] = *reinterpret_cast<const f16x8*>(p1 + 32 * s);
     };
 
-    store_half(0, 0, load_half(st, 0));
-    store_half(0, 1, load_half(st, 1));
-    f32x4 nx0 = load_half(st + G, 0), nx1 = load_half(st + G, 1);          // super-tile it+1: staged this iteration
-    f32x4 ny0 = load_half(st + 2 * G, 0), ny1 = load_half(st + 2 * G, 1);  // super-tile it+2
+    // SRC16 stages one 16-byte register per thread and super-tile, the fp32 source two
+    f32x4 nx0, nx1, ny0, ny1;
+    if (SRC16) {
+        store16(0, load16(st));
+        nx0 = load16(st + G);      // super-tile it+1: staged this iteration
+        ny0 = load16(st + 2 * G);  // super-tile it+2
+        nx1 = ny1 = nx0;
+    } else {
+        store_half(0, 0, load_half(st, 0));
+        store_half(0, 1, load_half(st, 1));
+        nx0 = load_half(st + G, 0); nx1 = load_half(st + G, 1);
+        ny0 = load_half(st + 2 * G, 0); ny1 = load_half(st + 2 * G, 1);
+    }
     __syncthreads();
     if (wave_active) read_frags(0);
     for (int it = 0; st < n_super; st += G, ++it) {
         const int nb = (it + 1) & 1;
-        store_half(nb, 0, nx0);
-        store_half(nb, 1, nx1);
-        nx0 = ny0; nx1 = ny1;
-        ny0 = load_half(st + 3 * G, 0);
-        ny1 = load_half(st + 3 * G, 1);
+        if (SRC16) {
+            store16(nb, nx0);
+            nx0 = ny0;
+            ny0 = load16(st + 3 * G);
+        } else {
+            store_half(nb, 0, nx0);
+            store_half(nb, 1, nx1);
+            nx0 = ny0; nx1 = ny1;
+            ny0 = load_half(st + 3 * G, 0);
+            ny1 = load_half(st + 3 * G, 1);
+        }
         if (wave_active) {
             const int64_t row0 = row_begin + st * 64;
             f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1052,16 +1120,18 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_in
             for (int s = 0; s < 4; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[s], bq[s], acc0, 0, 0, 0);
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[s], bq[s], acc1, 0, 0, 0);
-#if LBH_BQ_ABLATE >= 2  // timing-only builds: no epilogue
+#if LBH_BQ_ABLATE >= 2 && LBH_BQ_ABLATE != 3  // timing-only builds: no epilogue
             asm volatile("" ::"v"(acc0), "v"(acc1));
+#elif LBH_BQ_ABLATE == 3  // timing-only build: the threshold test alone, candidates are dropped
+            if (__any(lane_hit(acc0) | lane_hit(acc1))) asm volatile("s_nop 0");
 #else
             // one wave-wide test for both tiles; the row masks are only built for a tile that has a candidate
             // (without filters and inside the matrix they are all ones)
             const bool h0 = lane_hit(acc0), h1 = lane_hit(acc1);
             if (__any(h0 | h1)) {
                 const bool plain = !SINCE && !TAGS && row0 + 64 <= n;
-                if (__any(h0)) harvest(acc0, row0, plain ? 0xFFFFFFFFu : row_mask(row0));
-                if (__any(h1)) harvest(acc1, row0 + 32, plain ? 0xFFFFFFFFu : row_mask(row0 + 32));
+                if (__any(h0)) harvest(acc0, row0, plain ? 0xFFFFFFFFu : row_mask(row0), h0);
+                if (__any(h1)) harvest(acc1, row0 + 32, plain ? 0xFFFFFFFFu : row_mask(row0 + 32), h1);
             }
 #endif
         }
@@ -1673,7 +1743,7 @@ hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace&
     return hipGetLastError();
 }
 
-hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspace& ws, int nq, int k, int has_since,
+hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, int nq, int k, int has_since,
                                      int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, float norm_scale, hipStream_t s,
                                      hipEvent_t ev0, hipEvent_t ev1) {
     // one-time set-up (thread-safe: searches on different indexes may arrive concurrently)
@@ -1686,8 +1756,10 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspac
                              (const void*)scan_batched_kernel<false, true, false>, (const void*)scan_batched_kernel<false, false, false>,
                              (const void*)scan_batched_kernel<true, true, true>, (const void*)scan_batched_kernel<true, false, true>,
                              (const void*)scan_batched_kernel<false, true, true>, (const void*)scan_batched_kernel<false, false, true>,
-                             (const void*)scan_batched_f16_kernel<true, true>, (const void*)scan_batched_f16_kernel<true, false>,
-                             (const void*)scan_batched_f16_kernel<false, true>, (const void*)scan_batched_f16_kernel<false, false>};
+                             (const void*)scan_batched_f16_kernel<true, true, false>, (const void*)scan_batched_f16_kernel<true, false, false>,
+                             (const void*)scan_batched_f16_kernel<false, true, false>, (const void*)scan_batched_f16_kernel<false, false, false>,
+                             (const void*)scan_batched_f16_kernel<true, true, true>, (const void*)scan_batched_f16_kernel<true, false, true>,
+                             (const void*)scan_batched_f16_kernel<false, true, true>, (const void*)scan_batched_f16_kernel<false, false, true>};
         for (const void* f : fns) {
             const hipError_t e1 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BQ_LDS);
             if (e1 != hipSuccess) once_err = e1;
@@ -1717,22 +1789,27 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const lbh_workspac
     auto launch = [&](int64_t r0, int64_t r1, const uint32_t* seed) {
         const int64_t tiles = (r1 - r0 + 63) / 64;
         const dim3 g((unsigned)(tiles < n_cu ? tiles : n_cu));
-#define LBH_BSCAN_ARGS ix, ws.bq_qmat, nq, k, margin, since_ms, tag_mask, r0, r1, seed, ws.bq_cand, ws.bq_total, ws.flags
-        if (bf16 == 2) {  // one fp16 product per k-step
-            if (has_since && tag_mask) scan_batched_f16_kernel<true, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
-            else if (has_since) scan_batched_f16_kernel<true, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
-            else if (tag_mask) scan_batched_f16_kernel<false, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
-            else scan_batched_f16_kernel<false, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+#define LBH_BSCAN_ARGS ws.bq_qmat, nq, k, margin, since_ms, tag_mask, r0, r1, seed, ws.bq_cand, ws.bq_total, ws.flags
+        if (bf16 == 2 && emb16) {  // one fp16 product per k-step, operands streamed from the fp16 copy
+            if (has_since && tag_mask) scan_batched_f16_kernel<true, true, true><<<g, b, BQ_LDS, s>>>(ix, emb16, LBH_BSCAN_ARGS);
+            else if (has_since) scan_batched_f16_kernel<true, false, true><<<g, b, BQ_LDS, s>>>(ix, emb16, LBH_BSCAN_ARGS);
+            else if (tag_mask) scan_batched_f16_kernel<false, true, true><<<g, b, BQ_LDS, s>>>(ix, emb16, LBH_BSCAN_ARGS);
+            else scan_batched_f16_kernel<false, false, true><<<g, b, BQ_LDS, s>>>(ix, emb16, LBH_BSCAN_ARGS);
+        } else if (bf16 == 2) {    // one fp16 product per k-step, fp32 matrix converted while staging
+            if (has_since && tag_mask) scan_batched_f16_kernel<true, true, false><<<g, b, BQ_LDS, s>>>(ix, nullptr, LBH_BSCAN_ARGS);
+            else if (has_since) scan_batched_f16_kernel<true, false, false><<<g, b, BQ_LDS, s>>>(ix, nullptr, LBH_BSCAN_ARGS);
+            else if (tag_mask) scan_batched_f16_kernel<false, true, false><<<g, b, BQ_LDS, s>>>(ix, nullptr, LBH_BSCAN_ARGS);
+            else scan_batched_f16_kernel<false, false, false><<<g, b, BQ_LDS, s>>>(ix, nullptr, LBH_BSCAN_ARGS);
         } else if (bf16) {  // split-bf16 products on v_mfma_f32_32x32x16_bf16
-            if (has_since && tag_mask) scan_batched_kernel<true, true, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
-            else if (has_since) scan_batched_kernel<true, false, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
-            else if (tag_mask) scan_batched_kernel<false, true, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
-            else scan_batched_kernel<false, false, true><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+            if (has_since && tag_mask) scan_batched_kernel<true, true, true><<<g, b, BQ_LDS, s>>>(ix, LBH_BSCAN_ARGS);
+            else if (has_since) scan_batched_kernel<true, false, true><<<g, b, BQ_LDS, s>>>(ix, LBH_BSCAN_ARGS);
+            else if (tag_mask) scan_batched_kernel<false, true, true><<<g, b, BQ_LDS, s>>>(ix, LBH_BSCAN_ARGS);
+            else scan_batched_kernel<false, false, true><<<g, b, BQ_LDS, s>>>(ix, LBH_BSCAN_ARGS);
         } else {     // exact fp32 products on v_mfma_f32_32x32x2_f32
-            if (has_since && tag_mask) scan_batched_kernel<true, true, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
-            else if (has_since) scan_batched_kernel<true, false, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
-            else if (tag_mask) scan_batched_kernel<false, true, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
-            else scan_batched_kernel<false, false, false><<<g, b, BQ_LDS, s>>>(LBH_BSCAN_ARGS);
+            if (has_since && tag_mask) scan_batched_kernel<true, true, false><<<g, b, BQ_LDS, s>>>(ix, LBH_BSCAN_ARGS);
+            else if (has_since) scan_batched_kernel<true, false, false><<<g, b, BQ_LDS, s>>>(ix, LBH_BSCAN_ARGS);
+            else if (tag_mask) scan_batched_kernel<false, true, false><<<g, b, BQ_LDS, s>>>(ix, LBH_BSCAN_ARGS);
+            else scan_batched_kernel<false, false, false><<<g, b, BQ_LDS, s>>>(ix, LBH_BSCAN_ARGS);
         }
 #undef LBH_BSCAN_ARGS
     };
