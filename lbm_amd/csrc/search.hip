@@ -986,6 +986,9 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+#if LBH_BQ_ABLATE == 10
+__device__ long long lbh_k3_dbg[3][256][5];  // start, end, after prologue, (same), after loop: 100 MHz wall-clock ticks
+#endif
 template <bool SINCE, bool TAGS, bool SRC16>
 __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_index ix, const uint16_t* __restrict__ emb16,
                                                                        const double* __restrict__ qmat,
@@ -1009,6 +1012,10 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_in
     const int64_t n = row_end < ix.n ? row_end : ix.n;
     const f32x4* __restrict__ E = reinterpret_cast<const f32x4*>(ix.emb32);
 
+#if LBH_BQ_ABLATE == 10  // instrumented build (tools/scripts/k3_phases.py): phase times of every workgroup's first wave
+    const long long t_start = wall_clock64();
+    long long t_pro = 0, t_loop = 0;
+#endif
     if (tid < BQ_MAXQ) { qcnt[tid] = 0; qthr[tid] = (seed && tid < nq) ? seed[tid] : 0u; }
     f16x8 bq[4];  // B operand: k-step s holds dims 16s + 8h .. +7 of this lane's query
 #pragma unroll
@@ -1098,6 +1105,9 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_in
         ny0 = load_half(st + 2 * G, 0); ny1 = load_half(st + 2 * G, 1);
     }
     __syncthreads();
+#if LBH_BQ_ABLATE == 10
+    t_pro = wall_clock64();
+#endif
     if (wave_active) read_frags(0);
     for (int it = 0; st < n_super; st += G, ++it) {
         const int nb = (it + 1) & 1;
@@ -1120,7 +1130,7 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_in
             for (int s = 0; s < 4; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[s], bq[s], acc0, 0, 0, 0);
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[s], bq[s], acc1, 0, 0, 0);
-#if LBH_BQ_ABLATE >= 2 && LBH_BQ_ABLATE != 3  // timing-only builds: no epilogue
+#if LBH_BQ_ABLATE >= 2 && LBH_BQ_ABLATE != 3 && LBH_BQ_ABLATE < 10  // timing-only builds: no epilogue
             asm volatile("" ::"v"(acc0), "v"(acc1));
 #elif LBH_BQ_ABLATE == 3  // timing-only build: the threshold test alone, candidates are dropped
             if (__any(lane_hit(acc0) | lane_hit(acc1))) asm volatile("s_nop 0");
@@ -1138,6 +1148,9 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_in
         __syncthreads();
         if (wave_active) read_frags(nb);
     }
+#if LBH_BQ_ABLATE == 10
+    t_loop = wall_clock64();
+#endif
     // flush: final cut per query, then append to the query's flat candidate list in HBM
     if (wave_active) {
         bq_compact_all(bc, __ballot(lane < 32 && qactive && qcnt[myq] > 0));
@@ -1158,6 +1171,16 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_in
             if (lane < cnt) cand3[(size_t)q * BQ_PERQ + base + lane] = qbuf[(size_t)q * BQ_CAP + lane];
         }
     }
+#if LBH_BQ_ABLATE == 10
+    if (tid == 0) {  // slot: 0 = unseeded sample pass, 1 = seeded sample pass, 2 = full pass
+        const int slot = seed == nullptr ? 0 : (row_end >= ix.n ? 2 : 1);
+        lbh_k3_dbg[slot][blockIdx.x][0] = t_start;
+        lbh_k3_dbg[slot][blockIdx.x][1] = wall_clock64();
+        lbh_k3_dbg[slot][blockIdx.x][2] = t_pro;
+        lbh_k3_dbg[slot][blockIdx.x][3] = t_pro;
+        lbh_k3_dbg[slot][blockIdx.x][4] = t_loop;
+    }
+#endif
 }
 
 // Per-query seed threshold from the sample pass: (k-th best fp32 score of the sample) - margin.  The
@@ -1834,3 +1857,9 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* em
     select_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(ix, ws.bq_qmat, k, margin, ws.bq_cand, ws.bq_total, ws.flags, ws.bq_result_dev);
     return hipGetLastError();
 }
+
+#if LBH_BQ_ABLATE == 10
+extern "C" int lbh_debug_k3_times(long long* out) {  // instrumented build only: 3 x 256 x 5 ticks (tools/scripts/k3_phases.py)
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lbh_k3_dbg), sizeof(long long) * 3 * 256 * 5);
+}
+#endif
