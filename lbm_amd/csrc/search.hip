@@ -1038,8 +1038,12 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_in
         r = r < n ? r : n - 1;
         return __builtin_nontemporal_load(&E[r * 16 + sc4]);
     };
+    // LDS image of a super-tile: 64 rows of 128 B + 16 B pad (conflict-free ds_read_b128), THREE buffers in the space
+    // the other kernels use for two 272-byte-row buffers
+    constexpr int TS16 = 36, TILE16 = 64 * TS16;
+    static_assert(3 * TILE16 <= BQ_NBUF * BQ_TILE_F, "three fp16 tile buffers must fit the tile area");
     auto store_half = [&](int buf, int half, f32x4 v) {  // round-to-nearest-even conversion (the bound above needs it)
-        char* d = reinterpret_cast<char*>(tile + (size_t)buf * BQ_TILE_F + (half * 32 + srow) * BQ_TS) + 8 * sc4;
+        char* d = reinterpret_cast<char*>(tile + (size_t)buf * TILE16 + (half * 32 + srow) * TS16) + 8 * sc4;
         *reinterpret_cast<f16x4*>(d) = __builtin_convertvector(v, f16x4);
     };
     // SRC16: the index keeps an fp16 copy of the matrix (scan_mode 1): a super-tile is 8 KiB, one 16-byte load and
@@ -1052,7 +1056,7 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_in
         return __builtin_nontemporal_load(&E16[r * 8 + sc8]);
     };
     auto store16 = [&](int buf, f32x4 v) {
-        char* d = reinterpret_cast<char*>(tile + (size_t)buf * BQ_TILE_F + srow16 * BQ_TS) + 16 * sc8;
+        char* d = reinterpret_cast<char*>(tile + (size_t)buf * TILE16 + srow16 * TS16) + 16 * sc8;
         *reinterpret_cast<f32x4*>(d) = v;
     };
     bq_ctx bc;
@@ -1081,72 +1085,91 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_in
         if (qactive) thr_f = thr ? lbh_unord32(thr) : -__builtin_inff();
     };
 
-    f16x8 a0[4], a1[4];
-    auto read_frags = [&](int buf) {  // lane (j, h), k-step s: one ds_read_b128 at byte 32s + 16h of row j (conflict-free)
-        const char* p0 = reinterpret_cast<const char*>(tile + (size_t)buf * BQ_TILE_F + j * BQ_TS) + 16 * h;
-        const char* p1 = reinterpret_cast<const char*>(tile + (size_t)buf * BQ_TILE_F + (32 + j) * BQ_TS) + 16 * h;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a0[s] = *reinterpret_cast<const f16x8*>(p0 + 32 * s);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a1[s] = *reinterpret_cast<const f16x8*>(p1 + 32 * s);
-    };
-
-    // SRC16 stages one 16-byte register per thread and super-tile, the fp32 source two
-    f32x4 nx0, nx1, ny0, ny1;
+    // Software pipeline over super-tiles, one barrier each.  During iteration `it` a wave
+    //   1. issues the LDS reads of super-tile it+1's operands into the OTHER fragment set (that tile was staged during
+    //      iteration it-1 and is complete since the last barrier),
+    //   2. stages super-tile it+2 (global loads issued two iterations ago) into the third LDS buffer, whose last readers
+    //      finished before the last barrier, and issues the loads of super-tile it+4,
+    //   3. runs the 8 MFMAs of super-tile it on the fragment set read one iteration ago, then the threshold test.
+    // So the LDS read phase (64 KiB per super-tile and CU, ~0.25 us) overlaps the matrix phase (~0.2 us) instead of
+    // preceding it; with two buffers and one fragment set they alternated and a super-tile took ~0.6 us.
+    f16x8 fa[2][2][4];  // [set][32-claim tile][k-step]
+    f32x4 n0[2], n1[2];  // staged global loads: n?[it & 1] holds super-tile it+2 (fp32 source: two halves).  A second ring
+                         // level (four super-tiles in flight, m -> n register moves) was slower: 515 vs 449 us full pass
     if (SRC16) {
         store16(0, load16(st));
-        nx0 = load16(st + G);      // super-tile it+1: staged this iteration
-        ny0 = load16(st + 2 * G);  // super-tile it+2
-        nx1 = ny1 = nx0;
+        store16(1, load16(st + G));
+        n0[0] = load16(st + 2 * G);
+        n0[1] = load16(st + 3 * G);
+        n1[0] = n1[1] = n0[0];
     } else {
         store_half(0, 0, load_half(st, 0));
         store_half(0, 1, load_half(st, 1));
-        nx0 = load_half(st + G, 0); nx1 = load_half(st + G, 1);
-        ny0 = load_half(st + 2 * G, 0); ny1 = load_half(st + 2 * G, 1);
+        store_half(1, 0, load_half(st + G, 0));
+        store_half(1, 1, load_half(st + G, 1));
+        n0[0] = load_half(st + 2 * G, 0); n1[0] = load_half(st + 2 * G, 1);
+        n0[1] = load_half(st + 3 * G, 0); n1[1] = load_half(st + 3 * G, 1);
     }
     __syncthreads();
 #if LBH_BQ_ABLATE == 10
     t_pro = wall_clock64();
 #endif
-    if (wave_active) read_frags(0);
-    for (int it = 0; st < n_super; st += G, ++it) {
-        const int nb = (it + 1) & 1;
-        if (SRC16) {
-            store16(nb, nx0);
-            nx0 = ny0;
-            ny0 = load16(st + 3 * G);
-        } else {
-            store_half(nb, 0, nx0);
-            store_half(nb, 1, nx1);
-            nx0 = ny0; nx1 = ny1;
-            ny0 = load_half(st + 3 * G, 0);
-            ny1 = load_half(st + 3 * G, 1);
-        }
-        if (wave_active) {
-            const int64_t row0 = row_begin + st * 64;
-            f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            f32x16 acc1 = acc0;
+    int b_cur = 0, b_nxt = 1, b_stg = 2;
+    if (wave_active) {
+        const char* p0 = reinterpret_cast<const char*>(tile + j * TS16) + 16 * h;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[s], bq[s], acc0, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) fa[0][0][s] = *reinterpret_cast<const f16x8*>(p0 + 32 * s);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[s], bq[s], acc1, 0, 0, 0);
-#if LBH_BQ_ABLATE >= 2 && LBH_BQ_ABLATE != 3 && LBH_BQ_ABLATE < 10  // timing-only builds: no epilogue
-            asm volatile("" ::"v"(acc0), "v"(acc1));
-#elif LBH_BQ_ABLATE == 3  // timing-only build: the threshold test alone, candidates are dropped
-            if (__any(lane_hit(acc0) | lane_hit(acc1))) asm volatile("s_nop 0");
-#else
-            // one wave-wide test for both tiles; the row masks are only built for a tile that has a candidate
-            // (without filters and inside the matrix they are all ones)
-            const bool h0 = lane_hit(acc0), h1 = lane_hit(acc1);
-            if (__any(h0 | h1)) {
-                const bool plain = !SINCE && !TAGS && row0 + 64 <= n;
-                if (__any(h0)) harvest(acc0, row0, plain ? 0xFFFFFFFFu : row_mask(row0), h0);
-                if (__any(h1)) harvest(acc1, row0 + 32, plain ? 0xFFFFFFFFu : row_mask(row0 + 32), h1);
+        for (int s = 0; s < 4; ++s) fa[0][1][s] = *reinterpret_cast<const f16x8*>(p0 + 32 * TS16 * 4 + 32 * s);
+    }
+    while (st < n_super) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            if (st >= n_super) break;
+            if (wave_active) {  // lane (j, h), k-step s: one ds_read_b128 at byte 32s + 16h of row j
+                const char* p0 = reinterpret_cast<const char*>(tile + (size_t)b_nxt * TILE16 + j * TS16) + 16 * h;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) fa[p ^ 1][0][s] = *reinterpret_cast<const f16x8*>(p0 + 32 * s);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) fa[p ^ 1][1][s] = *reinterpret_cast<const f16x8*>(p0 + 32 * TS16 * 4 + 32 * s);
             }
+            if (SRC16) {
+                store16(b_stg, n0[p]);
+                n0[p] = load16(st + 4 * G);
+            } else {
+                store_half(b_stg, 0, n0[p]);
+                store_half(b_stg, 1, n1[p]);
+                n0[p] = load_half(st + 4 * G, 0);
+                n1[p] = load_half(st + 4 * G, 1);
+            }
+            if (wave_active) {
+                const int64_t row0 = row_begin + st * 64;
+                f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                f32x16 acc1 = acc0;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[p][0][s], bq[s], acc0, 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[p][1][s], bq[s], acc1, 0, 0, 0);
+#if LBH_BQ_ABLATE >= 2 && LBH_BQ_ABLATE != 3 && LBH_BQ_ABLATE < 10  // timing-only builds: no epilogue
+                asm volatile("" ::"v"(acc0), "v"(acc1));
+#elif LBH_BQ_ABLATE == 3  // timing-only build: the threshold test alone, candidates are dropped
+                if (__any(lane_hit(acc0) | lane_hit(acc1))) asm volatile("s_nop 0");
+#else
+                // one wave-wide test for both tiles; the row masks are only built for a tile that has a candidate
+                // (without filters and inside the matrix they are all ones)
+                const bool h0 = lane_hit(acc0), h1 = lane_hit(acc1);
+                if (__any(h0 | h1)) {
+                    const bool plain = !SINCE && !TAGS && row0 + 64 <= n;
+                    if (__any(h0)) harvest(acc0, row0, plain ? 0xFFFFFFFFu : row_mask(row0), h0);
+                    if (__any(h1)) harvest(acc1, row0 + 32, plain ? 0xFFFFFFFFu : row_mask(row0 + 32), h1);
+                }
 #endif
+            }
+            __syncthreads();
+            const int t = b_cur;
+            b_cur = b_nxt; b_nxt = b_stg; b_stg = t;
+            st += G;
         }
-        __syncthreads();
-        if (wave_active) read_frags(nb);
     }
 #if LBH_BQ_ABLATE == 10
     t_loop = wall_clock64();
