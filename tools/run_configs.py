@@ -52,7 +52,7 @@ def time_single(ix, qv, k, since, tmask, reps=60):
         scan.append(st.scan_ms * 1e-3)
         cand += st.candidates
     n = ix.size()
-    bpr = 256 + (8 if since != _hip.SINCE_NONE else 0) + (8 if tmask else 0)
+    bpr = st.bytes_per_row  # 256 (fp32 matrix) or 128 (fp16 copy), + 8 per fused mask
     s = float(np.median(scan))
     return {"claims": n, "top_k": k, "p50_ms": float(np.percentile(wall, 50) * 1e3), "p99_ms": float(np.percentile(wall, 99) * 1e3),
             "scan_us": s * 1e6, "bytes_per_claim": bpr, "scan_GBps": n * bpr / s / 1e9, "frac_of_8TBps": n * bpr / s / 8e12,
@@ -103,6 +103,9 @@ def main():
     p90 = synth.BASE_MS + 1000 * (9 * n // 10)
     out["config4_shard_single_query"] = {"k8": time_single(ix, qv, 8, _hip.SINCE_NONE, 0),
                                          "k64": time_single(ix, qv, 64, _hip.SINCE_NONE, 0)}
+    _hip.set_option("scan_mode", 1)  # opt-in: scans read the 128 B/claim fp16 copy (results identical)
+    out["config4_shard_single_query_fp16_copy"] = {"k8": time_single(ix, qv, 8, _hip.SINCE_NONE, 0)}
+    _hip.set_option("scan_mode", 0)
     out["config5_filtered_queries"] = {
         "since_p50_k8": time_single(ix, qv, 8, p50, 0), "since_p90_k8": time_single(ix, qv, 8, p90, 0),
         "tags3_k8": time_single(ix, qv, 8, _hip.SINCE_NONE, 0b111), "since_p50_tags3_k8": time_single(ix, qv, 8, p50, 0b111)}
@@ -111,8 +114,9 @@ def main():
     st.want_timing = 1
     single = out["config4_shard_single_query"]["k8"]["p50_ms"]
     res = {}
-    for mode, name, mfma_per_pair_dim in ((2, "fp16", 1), (1, "bf16_split3", 3), (0, "fp32_mfma", 1)):
-        _hip.set_option("bq_mode", mode)
+    for mode, name, mfma_per_pair_dim in ((2, "fp16", 1), (3, "fp16_from_fp16_copy", 1), (1, "bf16_split3", 3), (0, "fp32_mfma", 1)):
+        _hip.set_option("scan_mode", 1 if mode == 3 else 0)  # "mode 3" = fp16 scan fed from the fp16 copy (scan_mode 1)
+        _hip.set_option("bq_mode", 2 if mode == 3 else mode)
         for nq in ((256, 64, 16) if mode == 2 else (256,)):
             ix.search(qv[:nq], 8, _hip.SINCE_NONE, 0, st)
             wall, scan, err = [], [], 0.0
@@ -129,10 +133,11 @@ def main():
             res[f"{name}_q{nq}"] = {"claims": n, "queries": nq, "top_k": 8, "wall_ms": w * 1e3, "scan_ms": s * 1e3,
                                     "pairs_per_s": n * nq / w, "useful_TFLOPs": useful / s / 1e12,
                                     "mfma_TFLOPs_issued": issued / s / 1e12, "frac_of_dense_mfma_peak": issued / s / peak,
-                                    "mfma_peak_TFLOPs": peak / 1e12, "scan_GBps_of_claim_bytes": n * 256 / s / 1e9,
+                                    "mfma_peak_TFLOPs": peak / 1e12, "scan_GBps_of_claim_bytes": n * st.bytes_per_row / s / 1e9,
                                     "max_score_err": err, "path": st.path, "fallbacks": st.fallbacks,
                                     "vs_looping_single_query_path": single * nq / (w * 1e3)}
     _hip.set_option("bq_mode", 2)
+    _hip.set_option("scan_mode", 0)
     out["config3_batched_mfma"] = res
     print(json.dumps(out, indent=1))
 
