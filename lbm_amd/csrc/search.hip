@@ -110,6 +110,16 @@ __device__ __forceinline__ double exact_dot(const double* __restrict__ q, const 
     return acc;
 }
 
+// Same arithmetic for the re-rank of a handful of rows: one load per cache line of the 512-byte row goes out first, so
+// the row costs one HBM round trip instead of four in a row (the 8-deep loop above keeps the register count low and
+// would otherwise meet a new line, and a new miss, in every group; 32 loads at once spilled under the 1024-thread
+// launch bound).
+__device__ __forceinline__ double exact_dot_latency(const double* __restrict__ q, const double* __restrict__ row) {
+    const double t0 = row[0], t1 = row[16], t2 = row[32], t3 = row[48];
+    asm volatile("" ::"v"(t0), "v"(t1), "v"(t2), "v"(t3));
+    return exact_dot(q, row);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: fp32 streaming scan.  A wave reads one 64-row tile (16 KiB) per step as 16 fully coalesced
 // 1-KiB dwordx4 loads: lane l, load j covers floats [4c, 4c+4) of tile row 4j + g (c = l & 15,
@@ -402,7 +412,7 @@ __device__ void rerank_and_emit(uint64_t* xo, uint32_t* xr, int M, int k, const 
     __syncthreads();
     if (!have_scores) {
         for (int j = tid; j < M; j += SEL_THREADS) {
-            const double exact = exact_dot(qs, ix.emb64 + (size_t)xr[j] * 64);
+            const double exact = exact_dot_latency(qs, ix.emb64 + (size_t)xr[j] * 64);
             xo[j] = lbh_ord64(exact);
             const float err = (float)__builtin_fabs((double)lbh_unord32(j == tid ? scan_ord0 : scan_ord1) - exact);
             atomicMax(&sh_err, __builtin_bit_cast(uint32_t, err));
@@ -410,7 +420,12 @@ __device__ void rerank_and_emit(uint64_t* xo, uint32_t* xr, int M, int k, const 
     }
     for (int j = M + tid; j < n2; j += SEL_THREADS) { xo[j] = 0; xr[j] = PAD_ROW; }
     __syncthreads();
-    sort_exact(xo, xr, n2, tid, SEL_THREADS, ix.keys, BlockSync());
+    if (n2 <= 128) {  // the usual case (M ~ k): one wave sorts without block barriers
+        if (tid < 64) sort_exact(xo, xr, n2, tid, 64, ix.keys, WaveSync());
+        __syncthreads();
+    } else {
+        sort_exact(xo, xr, n2, tid, SEL_THREADS, ix.keys, BlockSync());
+    }
     const int cnt = M < k ? M : k;
     if (tid < cnt) {
         const uint32_t r = xr[tid];
@@ -446,6 +461,32 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
             const bool in = (uint32_t)(sbuf[i] >> 32) >= thr;
             const bool next_in = (i + 1 < E) && (uint32_t)(sbuf[i + 1] >> 32) >= thr;
             if (in && !next_in) sh_cnt = i + 1;
+        }
+        __syncthreads();
+        M = sh_cnt;
+    } else if (E <= 2 * LBH_MCAP) {
+        // the usual single-query case (512 blocks x k candidates): ONE pass over the global list into LDS; the
+        // min/max pass, the digit passes and the cut then read LDS (each global pass cost 1-2 us of L2 latency)
+        for (int e = tid; e < E; e += SEL_THREADS) sbuf[e] = cand[e];
+        __syncthreads();
+        if (E >= k) {
+            auto val = [&](int e, uint64_t* v) {
+                *v = sbuf[e] >> 32;
+                return true;
+            };
+            const uint32_t kth = (uint32_t)block_radix_select(E, 4, k, val, hist, &sh_krem, &sh_bin);
+            thr = lbh_ord32(lbh_unord32(kth) - margin);
+        }
+        uint64_t mine[2 * LBH_MCAP / SEL_THREADS];  // read everything before the survivors are packed into sbuf
+#pragma unroll
+        for (int i = 0; i < 2 * LBH_MCAP / SEL_THREADS; ++i) {
+            const int e = tid + i * SEL_THREADS;
+            mine[i] = e < E ? sbuf[e] : 0ull;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2 * LBH_MCAP / SEL_THREADS; ++i) {
+            if (tid + i * SEL_THREADS < E && (uint32_t)(mine[i] >> 32) >= thr) sbuf[atomicAdd(&sh_cnt, 1)] = mine[i];
         }
         __syncthreads();
         M = sh_cnt;
