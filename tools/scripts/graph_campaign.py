@@ -1,3 +1,5 @@
+"""Graph-level randomised campaign beyond the seeds the test suite runs (GPU box, repo root): incremental-ops and
+recency tests over 60 more seeds, hex and free-form hashes, single-query scan over the fp32 matrix and the fp16 copy."""
 import sys
 sys.path.insert(0, '.')
 sys.path.insert(0, 'tests')
@@ -5,10 +7,11 @@ import test_gpu_parity as t, test_recent as r
 from lbm_amd import _hip
 _hip.context()
 bad = 0
-for seed in range(100, 160):
+base = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+for seed in range(base, base + 60):
     for hexh in (True, False):
         try:
-            t.test_randomised_incremental_ops_vs_oracle(_hip, seed, hexh)
+            t.test_randomised_incremental_ops_vs_oracle(_hip, seed, hexh, seed & 1)
         except Exception as e:
             bad += 1; print('FAIL ops', seed, hexh, repr(e)[:300])
     try:
