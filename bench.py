@@ -75,14 +75,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # LBM_BENCH_REHEARSE_GLOO=1: rehearsal of the N > 1 flow on a box with fewer GPUs than ranks (every rank on GPU 0,
+    # collectives over gloo on host tensors).  Not a measurement: the line it prints says so in `data`.
+    rehearse = os.environ.get("LBM_BENCH_REHEARSE_GLOO") == "1"
+    if rehearse:
+        local_rank = 0
     os.environ.setdefault("LBM_HIP_DEVICE", str(local_rank))
 
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
+    coll_dev = "cpu" if rehearse else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from lbm_amd import _hip, synth
     from lbm_amd.sharded import ShardedSearcher
@@ -115,7 +124,7 @@ def main():
 
     queries = synth.make_queries(args.queries, seed=4321)
     qvecs = _hip.embed_batch(queries)
-    searcher = ShardedSearcher(ix.search_shard, rank, world, device=torch.device("cuda", local_rank))
+    searcher = ShardedSearcher(ix.search_shard, rank, world, device=None if rehearse else torch.device("cuda", local_rank))
     stats = _hip.Stats()
     every = max(1, args.time_every)
 
@@ -151,10 +160,10 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        lv = torch.tensor([live], dtype=torch.int64, device="cuda")
+        lv = torch.tensor([live], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(lv, op=dist.ReduceOp.SUM)
         total_live = int(lv.item())
     else:
@@ -189,7 +198,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 scan + f64 exact re-rank", "data": "synthetic",
+            "dtype": "f32 scan + f64 exact re-rank",
+            "data": "synthetic" if not rehearse else "synthetic; REHEARSAL (all ranks on one GPU, gloo): not a measurement",
             "config": {"workload": f"{args.claims}-claim shard per GPU (synthetic Zipf corpus, 1% retracted), "
                                    f"single-query compile_context ranking, top_k={args.top_k}, since_ms={args.since}",
                        "claims_per_gpu": args.claims, "live_claims_total": total_live, "top_k": args.top_k,
