@@ -82,6 +82,7 @@ def main():
         local_rank = 0
     os.environ.setdefault("LBM_HIP_DEVICE", str(local_rank))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
