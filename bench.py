@@ -13,6 +13,10 @@ Extra objects on the JSON line:
                 divided by the kernel's mean HIP-event duration on the library's stream.
   cpu_baseline  the CPU oracle (oracle/lb_oracle.c, a port of the reference's algorithm) timed on
                 one host core on a bounded sample of the same workload (rank 0, N = 1 only).
+  fp16_prefilter  side leg, N = 1 only, never `value`: the same steps with the opt-in scan_mode 1 (the scan reads a
+                128 B/claim fp16 copy of the matrix; the exact fp64 re-rank and so the results are unchanged).
+
+LBM_BENCH_REHEARSE_GLOO=1 rehearses the N > 1 flow on a box with fewer GPUs than ranks (see main()).
 """
 from __future__ import annotations
 

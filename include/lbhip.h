@@ -48,7 +48,7 @@ typedef struct lbh_stats {
                                  (total_ms).  Each event record costs a few microseconds of queue time. */
     int32_t path;             /* out: 0 = fp32 scan + exact re-rank, 1 = exact fp64 scan (fallback / paging), 2 = batched MFMA */
     int64_t rows_scanned;     /* out: live rows the scoring kernel read */
-    int64_t bytes_per_row;    /* out: algorithmic bytes per row for that kernel (256/264/272 or 512+..) */
+    int64_t bytes_per_row;    /* out: algorithmic bytes per row for that kernel (256/264/272; 128+.. with the fp16 copy; 512+.. exact path) */
     int64_t candidates;       /* out: rows that reached the exact fp64 re-rank */
     int32_t scan_launches;    /* out: number of scoring-kernel launches this call made */
     int32_t fallbacks;        /* out: times the fp32 path overflowed into the exact path */
