@@ -44,7 +44,7 @@ def parse():
     p.add_argument("--since", choices=["none", "p50", "p90"], default="none")
     p.add_argument("--queries", type=int, default=64)
     p.add_argument("--time-every", type=int, default=4, help="record HIP events around the scan on every N-th timed step")
-    p.add_argument("--cpu-sample", type=int, default=1_000_000, help="claims in the CPU-baseline sample (0 = skip)")
+    p.add_argument("--cpu-sample", type=int, default=2_000_000, help="claims in the CPU-baseline sample (0 = skip)")
     return p.parse_args()
 
 
