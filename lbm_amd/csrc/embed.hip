@@ -78,6 +78,19 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
+#ifdef LBH_K1_TIMING  // instrumented build (make ablate-style, tools/scripts/k1_phases.py): 10 ns ticks per phase, summed over all waves
+__device__ unsigned long long lbh_k1_dbg[8];
+#define K1_T(var) const long long var = wall_clock64()
+#define K1_ADD(slot, a, b) k1_t[slot] += (unsigned long long)((b) - (a))  // per wave; one atomic per slot at the end
+#define k1_count(g) k1_t[4] += (unsigned long long)(g)
+#else
+#define K1_T(var)
+#define K1_ADD(slot, a, b)
+#define k1_count(g)
+#endif
+constexpr int EMB_GROUP = 4;
+constexpr int EMB_HEAD = 128;
+
 __global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __restrict__ utf8,
                                                                 const int64_t* __restrict__ offsets, int64_t n,
                                                                 double* __restrict__ out64,
@@ -85,36 +98,64 @@ __global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __
     __shared__ double lut[256];
     __shared__ int tok_start[EMB_WAVES][TOK_RING];
     __shared__ int tok_end[EMB_WAVES][TOK_RING];
-    __shared__ uint32_t dig[EMB_WAVES][BATCH][16];  // 64 digest bytes per token, digest byte order
+    __shared__ int tok_claim[EMB_WAVES][TOK_RING];
+    __shared__ int64_t claim_off[EMB_WAVES][EMB_GROUP + 1];
+    __shared__ uint8_t head[EMB_WAVES][EMB_GROUP][EMB_HEAD];
+    __shared__ uint32_t dig[EMB_WAVES][BATCH][16];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    // lb/latent.py:52  (b / 127.5) - 1.0, evaluated once per block with IEEE fp64 divide
     lut[threadIdx.x & 255] = ((double)(threadIdx.x & 255) / 127.5) - 1.0;
     __syncthreads();
-
+#ifdef LBH_K1_TIMING
+    unsigned long long k1_t[6] = {0, 0, 0, 0, 0, 0};
+#endif
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int* ts = tok_start[wave];
     int* te = tok_end[wave];
+    int* tc = tok_claim[wave];
     const uint8_t* digb = reinterpret_cast<const uint8_t*>(&dig[wave][0][0]);
 
-    for (int64_t claim = (int64_t)blockIdx.x * EMB_WAVES + wave; claim < n; claim += (int64_t)gridDim.x * EMB_WAVES) {
-        const int64_t off0 = offsets[claim];
-        const int len = (int)(offsets[claim + 1] - off0);
-        const uint8_t* text = utf8 + off0;
+    for (int64_t g0 = ((int64_t)blockIdx.x * EMB_WAVES + wave) * EMB_GROUP; g0 < n;
+         g0 += (int64_t)gridDim.x * EMB_WAVES * EMB_GROUP) {
+        K1_T(c0);
+        const int gn = (int)(n - g0 < EMB_GROUP ? n - g0 : EMB_GROUP);
+        int64_t* cb = claim_off[wave];
+        if (lane <= EMB_GROUP) cb[lane] = offsets[g0 + (lane <= gn ? lane : gn)];
+        __builtin_amdgcn_wave_barrier();
+        {
+            uint32_t hb[EMB_GROUP][EMB_HEAD / 64];
+#pragma unroll
+            for (int c = 0; c < EMB_GROUP; ++c) {
+                const int64_t o = cb[c < gn ? c : gn], e = cb[c < gn ? c + 1 : gn];
+#pragma unroll
+                for (int u = 0; u < EMB_HEAD / 64; ++u) hb[c][u] = (o + 64 * u + lane < e) ? utf8[o + 64 * u + lane] : 0u;
+            }
+#pragma unroll
+            for (int c = 0; c < EMB_GROUP; ++c) {
+#pragma unroll
+                for (int u = 0; u < EMB_HEAD / 64; ++u) head[wave][c][64 * u + lane] = (uint8_t)hb[c][u];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        uint32_t has_tok = 0;
+        double acc[EMB_GROUP];
+#pragma unroll
+        for (int c = 0; c < EMB_GROUP; ++c) acc[c] = 0.0;
         int n_started = 0, n_ended = 0, n_done = 0;
-        uint64_t carry = 0;
-        double acc = 0.0;
 
         auto hash_batch = [&](int nb) {
+            K1_T(h0);
             const int t = lane >> 1, v = lane & 1;
             const bool act = t < nb;
             const int slot = (n_done + t) & (TOK_RING - 1);
             const int s = act ? ts[slot] : 0;
             const int tl = act ? te[slot] - s : 0;
+            const int ci = act ? tc[slot] : 0;
+            const int64_t base = cb[ci];
             const int total = tl + v;
             const int nblk = act ? ((total + 9 + 63) >> 6) : 0;
-            const uint8_t* tok = text + s;
+            const uint8_t* tok = utf8 + base + s;
             uint32_t st[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au,
                               0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
             for (int blk = 0; __any(blk < nblk); ++blk) {
@@ -139,43 +180,81 @@ __global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __
                 for (int i = 0; i < 8; ++i) dig[wave][t][v * 8 + i] = __builtin_bswap32(st[i]);
             }
             __builtin_amdgcn_wave_barrier();
-            for (int i = 0; i < nb; ++i) acc = acc + lut[digb[i * 64 + lane]];  // token order, lane = dim
+            K1_T(h1);
+            // token order, lane = dimension.  A batch holds its tokens claim by claim (the ring is filled in claim order),
+            // so each claim owns one contiguous run of it: the same tight loop as for a single claim, once per claim
+            const int my_ci = lane < nb ? tc[(n_done + lane) & (TOK_RING - 1)] : -1;
+#pragma unroll
+            for (int c = 0; c < EMB_GROUP; ++c) {
+                const uint64_t mk = __ballot(my_ci == c);
+                if (mk) {
+                    const int lo = __ffsll((long long)mk) - 1, hi = lo + __popcll(mk);
+                    for (int i = lo; i < hi; ++i) acc[c] = acc[c] + lut[digb[i * 64 + lane]];
+                }
+            }
             __builtin_amdgcn_wave_barrier();
+            K1_T(h2);
+            K1_ADD(1, h0, h1);
+            K1_ADD(2, h1, h2);
+            K1_ADD(5, 0, 1);  // hash batches
         };
 
-        for (int base = 0; base <= len; base += 64) {
-            const int p = base + lane;
-            const uint32_t c = (p < len) ? text[p] : 0u;
-            const uint64_t m = __ballot(is_word(c));
-            const uint64_t prev = (m << 1) | carry;
-            const uint64_t S = m & ~prev;   // token starts at this byte
-            const uint64_t E = ~m & prev;   // token ended just before this byte (exclusive end)
-            carry = m >> 63;
-            if ((S >> lane) & 1) ts[(n_started + __popcll(S & lt_mask)) & (TOK_RING - 1)] = p;
-            if ((E >> lane) & 1) te[(n_ended + __popcll(E & lt_mask)) & (TOK_RING - 1)] = p;
-            n_started += __popcll(S);
-            n_ended += __popcll(E);
-            __builtin_amdgcn_wave_barrier();
-            while (n_ended - n_done >= BATCH) {
-                hash_batch(BATCH);
-                n_done += BATCH;
+        for (int c = 0; c < gn; ++c) {
+            const uint8_t* text = utf8 + cb[c];
+            const int len = (int)(cb[c + 1] - cb[c]);
+            const int ended_before = n_ended;
+            uint64_t carry = 0;
+            for (int base = 0; base <= len; base += 64) {
+                const int p = base + lane;
+                const uint32_t ch = (p < len) ? (p < EMB_HEAD ? (uint32_t)head[wave][c][p] : (uint32_t)text[p]) : 0u;
+                const uint64_t m = __ballot(is_word(ch));
+                const uint64_t prev = (m << 1) | carry;
+                const uint64_t S = m & ~prev;
+                const uint64_t E = ~m & prev;
+                carry = m >> 63;
+                if ((S >> lane) & 1) ts[(n_started + __popcll(S & lt_mask)) & (TOK_RING - 1)] = p;
+                if ((E >> lane) & 1) {
+                    const int slot = (n_ended + __popcll(E & lt_mask)) & (TOK_RING - 1);
+                    te[slot] = p;
+                    tc[slot] = c;
+                }
+                n_started += __popcll(S);
+                n_ended += __popcll(E);
+                __builtin_amdgcn_wave_barrier();
+                while (n_ended - n_done >= BATCH) {
+                    hash_batch(BATCH);
+                    n_done += BATCH;
+                }
             }
+            if (n_ended > ended_before) has_tok |= 1u << c;
         }
         if (n_ended > n_done) hash_batch(n_ended - n_done);
-
-        // lb/latent.py:54-57
-        double ss = 0.0;
+        K1_T(c1);
 #pragma unroll
-        for (int d = 0; d < 64; ++d) {
-            const double x = readlane_f64(acc, d);
-            ss = ss + x * x;
+        for (int c = 0; c < EMB_GROUP; ++c) {
+            if (c < gn) {
+                double ss = 0.0;
+#pragma unroll
+                for (int d = 0; d < 64; ++d) {
+                    const double x = readlane_f64(acc[c], d);
+                    ss = ss + x * x;
+                }
+                const double nrm = __builtin_sqrt(ss);
+                double o = 0.0;
+                if (((has_tok >> c) & 1u) && nrm != 0.0) o = acc[c] / nrm;
+                out64[(g0 + c) * 64 + lane] = o;
+                if (out32) out32[(g0 + c) * 64 + lane] = (float)o;
+            }
         }
-        const double nrm = __builtin_sqrt(ss);
-        double o = 0.0;
-        if (n_ended > 0 && nrm != 0.0) o = acc / nrm;
-        out64[claim * 64 + lane] = o;
-        if (out32) out32[claim * 64 + lane] = (float)o;
+        K1_T(c2);
+        K1_ADD(0, c0, c1);
+        K1_ADD(3, c1, c2);
+        k1_count(gn);
     }
+#ifdef LBH_K1_TIMING
+    if (lane == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(&lbh_k1_dbg[i], k1_t[i]);
+#endif
 }
 
 // lb/latent.py:63  sum(x * y for x, y in zip(a, b)): one lane, strictly sequential, no FMA.
@@ -229,7 +308,7 @@ __global__ void scatter_u64_kernel(uint64_t* dst, const int64_t* __restrict__ ro
 hipError_t lbh_launch_embed(const uint8_t* utf8_dev, const int64_t* offsets_dev, int64_t n, double* out64_dev,
                             float* out32_dev, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    int64_t blocks = (n + EMB_WAVES - 1) / EMB_WAVES;
+    int64_t blocks = (n + EMB_WAVES * EMB_GROUP - 1) / (EMB_WAVES * EMB_GROUP);
     if (blocks > 256 * 32) blocks = 256 * 32;
     embed_kernel<<<dim3((unsigned)blocks), dim3(EMB_WAVES * 64), 0, s>>>(utf8_dev, offsets_dev, n, out64_dev, out32_dev);
     return hipGetLastError();
@@ -273,3 +352,13 @@ hipError_t lbh_launch_scatter_u64(uint64_t* dst, const int64_t* rows_dev, const 
     scatter_u64_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, s>>>(dst, rows_dev, vals_dev, n);
     return hipGetLastError();
 }
+
+#ifdef LBH_K1_TIMING
+extern "C" int lbh_debug_k1_times(unsigned long long* out, int reset) {  // instrumented build only
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(lbh_k1_dbg), z, sizeof z);
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lbh_k1_dbg), sizeof(unsigned long long) * 8);
+}
+#endif
