@@ -1,13 +1,13 @@
 // embed.hip -- K1: batched claim vectorisation (tokenise + 2x SHA-256 per token + in-order fp64
 // accumulation + L2 normalisation), bit-identical to lb/latent.py:34-57 of the reference.
 //
-// One wave64 per claim.  Lanes play three roles in turn:
+// One wave64 per group of EMB_GROUP consecutive claims (see embed_kernel).  Lanes play three roles in turn:
 //   1. byte classifier: 64 text bytes per step, __ballot -> token start / end bit masks
 //      ([A-Za-z0-9_]+, lb/latent.py:34; every byte >= 0x80 is a separator);
 //   2. hasher: lane l hashes token (l >> 1), variant (l & 1): sha256(t) or sha256(t + "\0")
 //      (lb/latent.py:47-48), 32 tokens = 64 digests per batch, lower-casing on the fly (:38);
 //   3. dimension owner: lane d accumulates v[d] += LUT[digest byte d] strictly in token order
-//      (:50-52), so the fp64 rounding sequence is the reference's.
+//      (:50-52) into the accumulator of the token's claim, so the fp64 rounding sequence is the reference's.
 // The norm is a sequential sum over d = 0..63 (mul, then add, no FMA: this file is built with
 // -ffp-contract=off), IEEE sqrt and IEEE divide (:54-57).  Rows are written as one coalesced
 // 512-B (fp64 master) and one 256-B (fp32 scan copy) store per claim.
@@ -88,8 +88,15 @@ __device__ unsigned long long lbh_k1_dbg[8];
 #define K1_ADD(slot, a, b)
 #define k1_count(g)
 #endif
+// One wave per GROUP of consecutive claims.  The hashing stage works on 32 tokens at a time (lane = token x variant)
+// and is where the time goes (8 of a claim's 11 us per wave with one claim per wave: tools/scripts/k1_phases.py); a
+// synthetic claim has 16 tokens on average, so half of those lanes idled.  The wave therefore streams the tokens of
+// EMB_GROUP consecutive claims through ONE token ring and hashes them in full batches, whatever claim they belong to
+// (0.62 batches per claim instead of 1); each token's digest is then added to ITS claim's accumulator, in token order
+// (lb/latent.py:50-52 is order-sensitive per claim; claims do not interact).  Token positions are relative to their
+// own claim's text.
 constexpr int EMB_GROUP = 4;
-constexpr int EMB_HEAD = 128;
+constexpr int EMB_HEAD = 128;  // bytes of every claim fetched up front (one round of independent loads per group)
 
 __global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __restrict__ utf8,
                                                                 const int64_t* __restrict__ offsets, int64_t n,
@@ -98,13 +105,15 @@ __global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __
     __shared__ double lut[256];
     __shared__ int tok_start[EMB_WAVES][TOK_RING];
     __shared__ int tok_end[EMB_WAVES][TOK_RING];
-    __shared__ int tok_claim[EMB_WAVES][TOK_RING];
-    __shared__ int64_t claim_off[EMB_WAVES][EMB_GROUP + 1];
-    __shared__ uint8_t head[EMB_WAVES][EMB_GROUP][EMB_HEAD];
-    __shared__ uint32_t dig[EMB_WAVES][BATCH][16];
+    __shared__ int tok_claim[EMB_WAVES][TOK_RING];            // which claim of the group (0..EMB_GROUP-1) a token belongs to
+    __shared__ int64_t claim_off[EMB_WAVES][EMB_GROUP + 1];   // text offsets of the group's claims (and the end of the last)
+    __shared__ uint8_t head[EMB_WAVES][EMB_GROUP][EMB_HEAD];  // first bytes of each claim: the classifier's 64-byte steps
+                                                              // would otherwise be a chain of dependent HBM round trips
+    __shared__ uint32_t dig[EMB_WAVES][BATCH][16];            // 64 digest bytes per token, digest byte order
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    // lb/latent.py:52  (b / 127.5) - 1.0, evaluated once per block with IEEE fp64 divide
     lut[threadIdx.x & 255] = ((double)(threadIdx.x & 255) / 127.5) - 1.0;
     __syncthreads();
 #ifdef LBH_K1_TIMING
@@ -138,8 +147,8 @@ __global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __
             }
             __builtin_amdgcn_wave_barrier();
         }
-        uint32_t has_tok = 0;
-        double acc[EMB_GROUP];
+        uint32_t has_tok = 0;    // bit c: claim c of the group has at least one token (an empty claim embeds to zeros)
+        double acc[EMB_GROUP];   // lane = dimension
 #pragma unroll
         for (int c = 0; c < EMB_GROUP; ++c) acc[c] = 0.0;
         int n_started = 0, n_ended = 0, n_done = 0;
@@ -209,8 +218,8 @@ __global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __
                 const uint32_t ch = (p < len) ? (p < EMB_HEAD ? (uint32_t)head[wave][c][p] : (uint32_t)text[p]) : 0u;
                 const uint64_t m = __ballot(is_word(ch));
                 const uint64_t prev = (m << 1) | carry;
-                const uint64_t S = m & ~prev;
-                const uint64_t E = ~m & prev;
+                const uint64_t S = m & ~prev;   // token starts at this byte
+                const uint64_t E = ~m & prev;   // token ended just before this byte (exclusive end)
                 carry = m >> 63;
                 if ((S >> lane) & 1) ts[(n_started + __popcll(S & lt_mask)) & (TOK_RING - 1)] = p;
                 if ((E >> lane) & 1) {
@@ -230,6 +239,7 @@ __global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __
         }
         if (n_ended > n_done) hash_batch(n_ended - n_done);
         K1_T(c1);
+        // lb/latent.py:54-57, claim by claim
 #pragma unroll
         for (int c = 0; c < EMB_GROUP; ++c) {
             if (c < gn) {
