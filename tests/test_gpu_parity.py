@@ -47,6 +47,35 @@ def test_embed_random_texts_vs_oracle(hip):
     assert got.tobytes() == want.tobytes()
 
 
+def test_embed_group_and_head_boundaries_vs_oracle(hip):
+    """K1 hashes the tokens of four consecutive claims in shared batches and assembles one-block messages a word at a
+    time from each claim's first 128 bytes; anything else takes the byte-wise path.  Directed cases around both
+    switches: tokens of every length 1..60 ending at byte 126..130 of their claim, upper case at every byte position,
+    lengths that are multiples of four, empty claims and token-free claims between full ones, groups cut short by the
+    end of the batch, and batches whose size is not a multiple of the group."""
+    letters = "ABCDEFGHIJKLMNOPQRSTUVWXYZ_0123456789abcdefghijklmnopqrstuvwxyz"
+    texts = []
+    for L in range(1, 61):
+        word = "".join(letters[(L + i) % len(letters)] for i in range(L))
+        for end in (126, 127, 128, 129, 130):
+            pad = end - L - 1
+            if pad >= 1:
+                texts.append("x" * pad + " " + word)          # the token ends exactly at byte `end`
+        texts.append(word)                                      # alone, at the very start
+        texts.append(word.swapcase() + " " + word.lower() + "!" + word.upper())
+    for pos in range(24):                                       # one upper-case byte at every position of a 24-byte token
+        t = list("abcdefghijklmnopqrstuvwx")
+        t[pos] = t[pos].upper()
+        texts.append("".join(t) + " z")
+    texts += ["", " ", "!!!", "é日😀", "a", "", "B c", "", "", "", "", "d" * 55, "e" * 56, "", "F" * 54 + " g"]
+    for n in (1, 2, 3, 4, 5, 7, 8, 9, len(texts)):
+        got = hip.embed_batch(texts[:n])
+        want = orc.embed_batch(texts[:n])
+        assert got.tobytes() == want.tobytes(), n
+    rev = texts[::-1]
+    assert hip.embed_batch(rev).tobytes() == orc.embed_batch(rev).tobytes()
+
+
 def test_cosine_golden(hip, golden_embed):
     from lbm_amd.latent import cosine, embed
     for c in golden_embed["cosine"]:
