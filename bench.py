@@ -16,6 +16,11 @@ Extra objects on the JSON line:
   fp16_prefilter  side leg, N = 1 only, never `value`: the same steps with the opt-in scan_mode 1 (the scan reads a
                 128 B/claim fp16 copy of the matrix; the exact fp64 re-rank and so the results are unchanged).
 
+Launching: ``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(one child process per GPU, before anything touches a GPU) and waits for them; under torchrun
+(``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``) each process is one rank.  Either way
+the run fails if the number of ranks is not ``--gpus``.
+
 LBM_BENCH_REHEARSE_GLOO=1 rehearses the N > 1 flow on a box with fewer GPUs than ranks (see main()).
 """
 from __future__ import annotations
@@ -23,6 +28,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -48,37 +55,130 @@ def parse():
     return p.parse_args()
 
 
+def host_cores() -> int:
+    """Worker threads for the all-cores leg: the box's CPU share (OMP_NUM_THREADS is set to it there), not the
+    whole machine that os.cpu_count() reports."""
+    for var in ("LBM_BENCH_CORES", "OMP_NUM_THREADS"):
+        v = os.environ.get(var, "")
+        if v.isdigit() and int(v) > 0:
+            return min(int(v), os.cpu_count() or 1)
+    return min(16, os.cpu_count() or 1)
+
+
 def cpu_baseline(sample_claims: int, top_k: int):
-    """Oracle (port of lb/latent.py + ContextGraph.compile) on 1 core, bounded sample."""
+    """Oracle (port of lb/latent.py + ContextGraph.compile) on a bounded sample: one core (the reference is a
+    single-threaded program) and all cores (claim-sharded threads + a top-k merge)."""
+    from concurrent.futures import ThreadPoolExecutor
     from lbm_amd import synth
+    from lbm_amd.sharded import merge_gathered, pack_local
     from oracle import lb_oracle as orc
+    cores = host_cores()
     ch = synth.make_chunk(0, sample_claims, seed=1234, chunk_index=0, real_sha_keys=False)
+    n = ch.n
+    cuts = [n * i // cores for i in range(cores + 1)]
+    # embedding: the whole sample on all cores (ctypes drops the GIL), a tenth of it on one core for the 1-core rate
+    emb = np.zeros((n, 64), dtype=np.float64)
+
+    def embed_part(i):
+        a, b = cuts[i], cuts[i + 1]
+        off = ch.offsets[a: b + 1]
+        emb[a:b] = orc.embed_batch_packed(ch.blob[off[0]: off[-1] + 1], off - off[0])
+
     t0 = time.perf_counter()
-    emb = orc.embed_batch_packed(ch.blob, ch.offsets)
-    t_embed = time.perf_counter() - t0
-    packed = orc.pack_texts(ch.hashes())
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(embed_part, range(cores)))
+    t_embed_all = time.perf_counter() - t0
+    n1 = max(1, n // 10)
+    t0 = time.perf_counter()
+    e1 = orc.embed_batch_packed(ch.blob[: ch.offsets[n1] + 1], ch.offsets[: n1 + 1])
+    t_embed_1 = time.perf_counter() - t0
+    assert e1.tobytes() == emb[:n1].tobytes()
+    keys_hex = ch.hashes()
+    packed = orc.pack_texts(keys_hex)
     retr = ch.retracted.astype(np.uint8)
     queries = synth.make_queries(8, seed=4321)
     qv = [orc.embed_array(q) for q in queries]
     t0 = time.perf_counter()
-    for v in qv:
-        orc.compile_arrays(emb, ch.created_ms, retr, None, v, top_k, None, packed_keys=packed)
+    one = [orc.compile_arrays(emb, ch.created_ms, retr, None, v, top_k, None, packed_keys=packed) for v in qv]
     t_rank = time.perf_counter() - t0
+    # all cores: each thread ranks its contiguous shard, the per-shard top-k lists are merged like the GPUs' lists
+    parts = []
+    for i in range(cores):
+        a, b = cuts[i], cuts[i + 1]
+        parts.append((a, np.ascontiguousarray(emb[a:b]), np.ascontiguousarray(ch.created_ms[a:b]), np.ascontiguousarray(retr[a:b]),
+                      orc.pack_texts(keys_hex[a:b]), ch.keys[a:b]))
+
+    def rank_part(arg):
+        (a, e, cm, rt, pk, kb), v = arg
+        idx, sc = orc.compile_arrays(e, cm, rt, None, v, top_k, None, packed_keys=pk)
+        return pack_local(sc, (idx + a).astype(np.uint64), kb[idx], top_k)
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        many = []
+        for v in qv:
+            lists = list(ex.map(rank_part, [(p, v) for p in parts]))
+            many.append(merge_gathered(np.stack(lists), top_k))
+    t_rank_all = time.perf_counter() - t0
+    for (i1, s1), (ia, sa, _) in zip(one, many):
+        assert i1.tolist() == ia.tolist() and s1.tobytes() == sa.tobytes()  # sharded == unsharded, bit for bit
     live = int((~ch.retracted).sum())
     return {
         "value": live * len(qv) / t_rank, "unit": "claims scored/s", "cores": 1, "kind": "port",
         "sample": f"{sample_claims} claims ({live} live) x {len(qv)} queries, top_k={top_k}: "
-                  f"score every claim in fp64 + full sort like the reference ({t_rank:.2f} s); "
-                  f"embedding the sample took {t_embed:.2f} s = {sample_claims / t_embed:.0f} claims/s",
-        "embed_claims_per_s": sample_claims / t_embed,
+                  f"score every claim in fp64 + full sort like the reference ({t_rank:.2f} s on 1 core, "
+                  f"{t_rank_all:.2f} s on {cores} cores, claim-sharded threads + top-k merge, identical results)",
+        "all_cores": {"value": live * len(qv) / t_rank_all, "unit": "claims scored/s", "cores": cores},
+        "embed_claims_per_s": n1 / t_embed_1,
+        "embed_claims_per_s_all_cores": {"value": n / t_embed_all, "cores": cores},
     }
+
+
+def launch_ranks(args) -> int:
+    """``--gpus N`` without a launcher: start the N ranks as child processes (nothing in this process has touched a
+    GPU), wait for all of them, fail if any fails.  Rank 0 prints the JSON line on the inherited stdout."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0])] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:  # one rank died: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but this process is one of WORLD_SIZE={world} ranks")
     # LBM_BENCH_REHEARSE_GLOO=1: rehearsal of the N > 1 flow on a box with fewer GPUs than ranks (every rank on GPU 0,
     # collectives over gloo on host tensors).  Not a measurement: the line it prints says so in `data`.
     rehearse = os.environ.get("LBM_BENCH_REHEARSE_GLOO") == "1"
@@ -89,7 +189,9 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    have_gpu = torch.cuda.is_available()  # False only in the CPU rehearsal of the launcher (tests/bench_cpu_harness.py)
+    if have_gpu or not rehearse:
+        torch.cuda.set_device(local_rank)
     coll_dev = "cpu" if rehearse else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -116,8 +218,7 @@ def main():
                               real_sha_keys=False)
         t1 = time.perf_counter()
         ids = ix.add_texts(ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)
-        for i in np.nonzero(ch.retracted)[0].tolist():
-            ix.retract(int(ids[i]))
+        ix.retract_many(ids[ch.retracted])  # 1 % of the claims: one compaction kernel per chunk
         t2 = time.perf_counter()
         t_gen += t1 - t0
         t_add += t2 - t1
@@ -145,7 +246,8 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if have_gpu:
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
@@ -225,7 +327,7 @@ def main():
             _hip.set_option("scan_mode", 1)
             for i in range(args.warmup):
                 ix.search_shard(qvecs[i % len(queries)], args.top_k, since, 0, stats)
-            torch.cuda.synchronize()
+            fence()
             h_ms, h_timed = 0.0, 0
             h0 = time.perf_counter()
             for i in range(args.steps):
@@ -234,7 +336,7 @@ def main():
                 if i % every == 0:
                     h_ms += stats.scan_ms
                     h_timed += 1
-            torch.cuda.synchronize()
+            fence()
             h_el = time.perf_counter() - h0
             _hip.set_option("scan_mode", 0)
             h_bpr = bytes_per_row - 128

@@ -87,7 +87,11 @@ int lbh_set_option(lbh_ctx* ctx, const char* name, int64_t value);
  * both SHA-256 digests per token (:47-48), the in-order fp64 accumulation (:50-52)
  * and the normalisation (:54-57) all run on the GPU. */
 int lbh_embed_batch(lbh_ctx* ctx, const uint8_t* utf8, const int64_t* offsets, int64_t n, double* out_f64);
-/* Same, device pointers in and out (text already resident in HBM); out_f32_dev may be NULL. */
+/* embed(text, dim) for 1 <= dim <= 64 (lb/latent.py:41-57 with a caller-chosen dim): only the first `dim` digest
+ * bytes of a token are accumulated (:50-52) and the norm runs over those `dim` components (:54).  out_f64 still
+ * receives n x 64 doubles; components >= dim are 0.  dim = 64 is lbh_embed_batch. */
+int lbh_embed_batch_dim(lbh_ctx* ctx, const uint8_t* utf8, const int64_t* offsets, int64_t n, int dim, double* out_f64);
+/* Same as lbh_embed_batch, device pointers in and out (text already resident in HBM); out_f32_dev may be NULL. */
 int lbh_embed_batch_dev(lbh_ctx* ctx, const uint8_t* utf8_dev, const int64_t* offsets_dev, int64_t n,
                         int64_t total_bytes, double* out_f64_dev, float* out_f32_dev);
 
@@ -115,6 +119,10 @@ int lbh_index_add(lbh_index* idx, int64_t n, const double* emb_f64, const uint8_
 /* replaces ContextGraph.retract (lb/context_graph.py:84-89): the row is removed from the
  * scanned arrays (the reference drops the embedding and skips the claim, :89,:107). */
 int lbh_index_retract(lbh_index* idx, uint64_t id);
+/* Batched form of lbh_index_retract: what a loader or a reconciling mirror issues after many ContextGraph.retract
+ * calls (lb/context_graph.py:84-89 in a loop).  The n rows leave the scanned arrays in ONE compaction kernel
+ * (surviving rows of the cut-off tail fill the holes).  Unknown or repeated ids fail the call before anything changes. */
+int lbh_index_retract_many(lbh_index* idx, int64_t n, const uint64_t* ids);
 /* Rewrites the per-claim metadata that compile() filters on (a caller mutated Claim.created_ms / tags). */
 int lbh_index_update_meta(lbh_index* idx, uint64_t id, int64_t created_ms, uint64_t tagmask, const uint8_t* hashkey);
 /* Bulk rewrite of the tie-break keys of n live claims (ids[n], hashkey n x 32 bytes).  Used by the
@@ -124,6 +132,8 @@ int lbh_index_set_keys(lbh_index* idx, int64_t n, const uint64_t* ids, const uin
 int lbh_index_size(lbh_index* idx, int64_t* out_live);
 /* Copies the cached fp64 embedding of a claim (the reference's _embedding_cache[h]). */
 int lbh_index_get_embedding(lbh_index* idx, uint64_t id, double* out64);
+/* Same for n claims in one gather kernel + one copy: out_f64 receives n x 64 doubles. */
+int lbh_index_get_embeddings(lbh_index* idx, int64_t n, const uint64_t* ids, double* out_f64);
 
 /* replaces the scoring loop + sort + cut of ContextGraph.compile (lb/context_graph.py:104-121)
  * for nq query vectors (q_f64 = nq x 64 doubles, e.g. from lbh_embed_batch).

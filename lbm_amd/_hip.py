@@ -28,9 +28,10 @@ LIB_PATH = os.environ.get("LBM_HIP_LIB") or os.path.join(_HERE, "liblbhip.so")  
 
 EXPORTS = [
     "lbh_init", "lbh_shutdown", "lbh_last_error", "lbh_version", "lbh_device_name", "lbh_set_option",
-    "lbh_embed_batch", "lbh_embed_batch_dev", "lbh_cosine",
+    "lbh_embed_batch", "lbh_embed_batch_dim", "lbh_embed_batch_dev", "lbh_cosine",
     "lbh_index_create", "lbh_index_destroy", "lbh_index_reserve", "lbh_index_add", "lbh_index_retract",
-    "lbh_index_update_meta", "lbh_index_set_keys", "lbh_index_size", "lbh_index_get_embedding",
+    "lbh_index_retract_many", "lbh_index_update_meta", "lbh_index_set_keys", "lbh_index_size", "lbh_index_get_embedding",
+    "lbh_index_get_embeddings",
     "lbh_index_search", "lbh_index_search_text", "lbh_index_search_shard",
     "lbh_index_recent", "lbh_index_set_order", "lbh_merge_topk",
 ]
@@ -110,6 +111,7 @@ def load_library() -> ctypes.CDLL:
         L.lbh_device_name.argtypes = [_vp, ctypes.c_char_p, ctypes.c_int]
         L.lbh_set_option.argtypes = [_vp, ctypes.c_char_p, _i64]
         L.lbh_embed_batch.argtypes = [_vp, _vp, _vp, _i64, _vp]
+        L.lbh_embed_batch_dim.argtypes = [_vp, _vp, _vp, _i64, ctypes.c_int, _vp]
         L.lbh_embed_batch_dev.argtypes = [_vp, _vp, _vp, _i64, _i64, _vp, _vp]
         L.lbh_cosine.argtypes = [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(ctypes.c_double)]
         L.lbh_index_create.argtypes = [_vp, ctypes.POINTER(_vp)]
@@ -117,6 +119,8 @@ def load_library() -> ctypes.CDLL:
         L.lbh_index_reserve.argtypes = [_vp, _i64]
         L.lbh_index_add.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
         L.lbh_index_retract.argtypes = [_vp, _u64]
+        L.lbh_index_retract_many.argtypes = [_vp, _i64, _vp]
+        L.lbh_index_get_embeddings.argtypes = [_vp, _i64, _vp, _vp]
         L.lbh_index_update_meta.argtypes = [_vp, _u64, _i64, _u64, _vp]
         L.lbh_index_set_keys.argtypes = [_vp, _i64, _vp, _vp]
         L.lbh_index_size.argtypes = [_vp, ctypes.POINTER(_i64)]
@@ -211,19 +215,20 @@ def pack_texts(texts: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
     return blob, offsets
 
 
-def embed_batch_packed(blob: np.ndarray, offsets: np.ndarray) -> np.ndarray:
+def embed_batch_packed(blob: np.ndarray, offsets: np.ndarray, dim: int = DIM) -> np.ndarray:
     n = int(offsets.shape[0]) - 1
     out = np.empty((n, DIM), dtype=np.float64)
     if n > 0:
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
-        _check(load_library().lbh_embed_batch(context(), _ptr(blob), _ptr(offsets), n, _ptr(out)))
+        _check(load_library().lbh_embed_batch_dim(context(), _ptr(blob), _ptr(offsets), n, int(dim), _ptr(out)))
     return out
 
 
-def embed_batch(texts: Sequence[str]) -> np.ndarray:
+def embed_batch(texts: Sequence[str], dim: int = DIM) -> np.ndarray:
+    """(n, 64) float64; with dim < 64 the components >= dim are 0 (callers slice [:dim])."""
     blob, offsets = pack_texts(texts)
-    return embed_batch_packed(blob, offsets)
+    return embed_batch_packed(blob, offsets, dim)
 
 
 def embed_batch_dev(utf8_ptr: int, offsets_ptr: int, n: int, total_bytes: int, out64_ptr: int, out32_ptr: int = 0):
@@ -301,6 +306,11 @@ class Index:
     def retract(self, cid: int) -> None:
         _check(self._L.lbh_index_retract(self._h, int(cid)))
 
+    def retract_many(self, cids) -> None:
+        ids = np.ascontiguousarray(cids, dtype=np.uint64).reshape(-1)
+        if ids.shape[0]:
+            _check(self._L.lbh_index_retract_many(self._h, ids.shape[0], _ptr(ids)))
+
     def update_meta(self, cid: int, created_ms: int, tagmask: int, key: bytes) -> None:
         k = np.frombuffer(key, dtype=np.uint8).copy()
         _check(self._L.lbh_index_update_meta(self._h, int(cid), int(created_ms), int(tagmask), _ptr(k)))
@@ -331,6 +341,13 @@ class Index:
     def get_embedding(self, cid: int) -> np.ndarray:
         out = np.empty(DIM, dtype=np.float64)
         _check(self._L.lbh_index_get_embedding(self._h, int(cid), _ptr(out)))
+        return out
+
+    def get_embeddings(self, cids) -> np.ndarray:
+        ids = np.ascontiguousarray(cids, dtype=np.uint64).reshape(-1)
+        out = np.empty((ids.shape[0], DIM), dtype=np.float64)
+        if ids.shape[0]:
+            _check(self._L.lbh_index_get_embeddings(self._h, ids.shape[0], _ptr(ids), _ptr(out)))
         return out
 
     def search(self, q: np.ndarray, k: int, since_ms: int = SINCE_NONE, tag_mask: int = 0,

@@ -64,6 +64,35 @@ _HEXRUN = re.compile(r"[0-9a-f]*\Z")
 MAX_TAG_BITS = 64
 
 
+class _TagList(list):
+    """``Claim.tags`` of a claim that lives in a graph: a list that reports in-place edits (``tags.append(..)``,
+    ``tags[:] = ..``) to the graph, so the device-side tag mask of the opt-in ``tags=`` filter cannot go stale."""
+
+    __slots__ = ("_lbm_claim",)
+
+    def _ping(self) -> None:
+        c = getattr(self, "_lbm_claim", None)
+        if c is not None:
+            owner = c.__dict__.get("_lbm_owner")
+            if owner is not None and c.__dict__.get("tags") is self:
+                owner[0]._touch(owner[1])
+
+    def _wrap(name):  # noqa: N805
+        base = getattr(list, name)
+
+        def method(self, *a, **kw):
+            r = base(self, *a, **kw)
+            self._ping()
+            return r
+        method.__name__ = name
+        return method
+
+    for _n in ("append", "extend", "insert", "remove", "pop", "clear", "sort", "reverse", "__setitem__", "__delitem__",
+               "__iadd__", "__imul__"):
+        locals()[_n] = _wrap(_n)
+    del _n, _wrap
+
+
 @dataclass
 class Claim:  # lb/context_graph.py:10-43
     claim_hash: str
@@ -75,6 +104,9 @@ class Claim:  # lb/context_graph.py:10-43
     retracted: bool = False
 
     def __setattr__(self, name: str, value: Any) -> None:
+        if name == "tags" and type(value) is list:
+            value = _TagList(value)
+            value._lbm_claim = self
         object.__setattr__(self, name, value)
         owner = self.__dict__.get("_lbm_owner")
         if owner is not None and name in ("retracted", "created_ms", "tags", "text"):
@@ -210,6 +242,9 @@ class _EmbeddingCacheView:
         v = np.ascontiguousarray(vec, dtype=np.float64)
         if v.shape != (_hip.DIM,):
             raise ValueError("embedding must have 64 components")
+        # what lbh_index_add would refuse is refused here, at the assignment, not at some later sync
+        if not np.all(np.isfinite(v)) or not float(np.sqrt(np.sum(v * v))) <= 1e15:
+            raise ValueError("embedding must be finite with a norm of at most 1e15")
         g._drop_row(h, park=False)
         g._parked[h] = v
         g._touch(h)
@@ -267,6 +302,7 @@ class ContextGraph:
         self._hash_of: Dict[int, str] = {}
         self._meta: Dict[str, Tuple[int, int]] = {}  # hash -> (created_ms, tagmask) as stored on device
         self._parked: Dict[str, np.ndarray] = {}     # cached vectors of claims currently not scanned
+        self._discard: Dict[str, None] = {}          # hashes whose cached vector retract() / add_claim() dropped since the last sync
         self._tag_bits: Dict[str, int] = {}
         self._tag_overflow = False
         self._rank_keys = False
@@ -335,19 +371,59 @@ class ContextGraph:
 
     @_locked
     def _sync(self) -> None:
-        """Bring the device index in line with ``claims`` (only dirty hashes are looked at)."""
+        """Bring the device index in line with ``claims`` (only dirty hashes are looked at).
+
+        Device calls are batched: every row that leaves the scanned arrays goes in ONE ``retract_many`` (one compaction
+        kernel), every new text in ONE K1 launch.  Bookkeeping is committed only after the device call it describes has
+        succeeded; if a call fails, every hash of the batch is dirty again and parked vectors / pending texts are still
+        in place, so a later ``compile`` retries instead of silently missing claims."""
         if not self._dirty:
             if self._keys_stale:
                 self._refresh_rank_keys()
             return
-        dirty, self._dirty = list(self._dirty.keys()), {}
+        dirty = list(self._dirty.keys())
+        self._dirty = {}
+        try:
+            self._reconcile(dirty)
+        except BaseException:
+            for h in dirty:
+                self._dirty.setdefault(h, None)
+            raise
+
+    def _reconcile(self, dirty: List[str]) -> None:
+        claims = self.claims
+        # stage 1: rows that leave the device.  A hash in _discard lost its vector (retract / add_claim of an existing
+        # hash, :82 / :89); a claim that is merely not live right now (flag flipped or dict entry removed by hand) keeps
+        # its vector parked on the host.
+        drop_park: List[str] = []
+        drop_free: List[str] = []
+        for h in dirty:
+            if h not in self._id_of:
+                continue
+            if h in self._discard:
+                drop_free.append(h)
+                continue
+            c = claims.get(h)
+            if c is None or getattr(c, "retracted", False):
+                drop_park.append(h)
+        if drop_park or drop_free:
+            index = self._index
+            vecs = index.get_embeddings([self._id_of[h] for h in drop_park]) if drop_park else None
+            index.retract_many([self._id_of[h] for h in drop_park + drop_free])
+            for i, h in enumerate(drop_park):
+                self._parked[h] = vecs[i].copy()
+            for h in drop_park + drop_free:
+                self._hash_of.pop(self._id_of.pop(h), None)
+                self._meta.pop(h, None)
+        for h in dirty:
+            if self._discard.pop(h, 0) is None:
+                self._parked.pop(h, None)
+        # stage 2: metadata edits of rows that stay, and the claims that (re-)enter
         new_text: List[Tuple[str, str, Claim]] = []
         new_vec: List[Tuple[str, np.ndarray, Claim]] = []
         for h in dirty:
-            c = self.claims.get(h)
-            live = c is not None and not getattr(c, "retracted", False)
-            if not live:
-                self._drop_row(h, park=True)
+            c = claims.get(h)
+            if c is None or getattr(c, "retracted", False):
                 self._pending_text.pop(h, None)
                 continue
             if h in self._id_of:
@@ -360,9 +436,9 @@ class ContextGraph:
                     self._meta[h] = (cm, tm)
                 continue
             if h in self._parked:
-                new_vec.append((h, self._parked.pop(h), c))
+                new_vec.append((h, self._parked[h], c))
             else:
-                new_text.append((h, self._pending_text.pop(h, c.text), c))
+                new_text.append((h, self._pending_text.get(h, c.text), c))
         if new_vec:
             hs = [h for h, _, _ in new_vec]
             created = np.array([int(c.created_ms) for _, _, c in new_vec], dtype=np.int64)
@@ -370,6 +446,8 @@ class ContextGraph:
             keys = self._keys_of(hs)
             ids = self._index.add_vectors(np.stack([v for _, v, _ in new_vec]), created, tmask, keys)
             self._register(hs, ids, created, tmask)
+            for h in hs:
+                self._parked.pop(h, None)
         if new_text:
             hs = [h for h, _, _ in new_text]
             blob, offsets = _hip.pack_texts([t for _, t, _ in new_text])
@@ -378,6 +456,8 @@ class ContextGraph:
             keys = self._keys_of(hs)
             ids = self._index.add_texts(blob, offsets, created, tmask, keys)
             self._register(hs, ids, created, tmask)
+            for h in hs:
+                self._pending_text.pop(h, None)
         if self._rank_keys and (self._keys_stale or new_vec or new_text):
             self._refresh_rank_keys()
 
@@ -414,9 +494,9 @@ class ContextGraph:
     ) -> None:
         if created_ms is None:
             created_ms = int(time.time() * 1000)
-        # the reference re-embeds on every add_claim (:82), also when the hash already exists
-        self._drop_row(claim_hash, park=False)
-        self._parked.pop(claim_hash, None)
+        # the reference re-embeds on every add_claim (:82), also when the hash already exists: whatever vector the
+        # hash had is discarded at the next sync (batched with every other row that leaves the device)
+        self._discard[claim_hash] = None
         self._pending_text[claim_hash] = text
         self.claims[claim_hash] = Claim(
             claim_hash=claim_hash,
@@ -432,10 +512,10 @@ class ContextGraph:
     def retract(self, claim_hash: str) -> None:
         c = self.claims.get(claim_hash)
         if c:
-            c.retracted = True
-            # the reference frees the cached embedding here (:89)
-            self._drop_row(claim_hash, park=False)
-            self._parked.pop(claim_hash, None)
+            c.retracted = True  # marks the hash dirty
+            # the reference frees the cached embedding here (:89); the device row goes at the next sync, in one
+            # compaction with every other retract since the last query
+            self._discard[claim_hash] = None
             self._pending_text.pop(claim_hash, None)
 
     def compile(

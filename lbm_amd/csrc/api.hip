@@ -83,6 +83,8 @@ struct lbh_index {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // per index: searches on two indexes may run concurrently
     void* staging = nullptr;  // pinned host staging
     int64_t staging_cap = 0;
+    void* dscratch = nullptr;  // device scratch of the batched mutators (row lists, pairs, gathered rows); grow-only
+    int64_t dscratch_cap = 0;
 };
 
 namespace {
@@ -152,6 +154,17 @@ int ensure_staging(lbh_index* ix, int64_t bytes) {
     int64_t cap = std::max<int64_t>(bytes, 1 << 20);
     HIP_TRY(hipHostMalloc(&ix->staging, (size_t)cap, hipHostMallocDefault));
     ix->staging_cap = cap;
+    return LBH_OK;
+}
+
+int ensure_dscratch(lbh_index* ix, int64_t bytes) {
+    if (bytes <= ix->dscratch_cap) return LBH_OK;
+    if (ix->dscratch) (void)hipFree(ix->dscratch);
+    ix->dscratch = nullptr;
+    ix->dscratch_cap = 0;
+    const int64_t cap = std::max<int64_t>(bytes + bytes / 2, 1 << 16);
+    HIP_TRY(hipMalloc(&ix->dscratch, (size_t)cap));
+    ix->dscratch_cap = cap;
     return LBH_OK;
 }
 
@@ -459,7 +472,12 @@ int lbh_set_option(lbh_ctx* c, const char* name, int64_t value) {
 }
 
 int lbh_embed_batch(lbh_ctx* c, const uint8_t* utf8, const int64_t* offsets, int64_t n, double* out_f64) {
+    return lbh_embed_batch_dim(c, utf8, offsets, n, LBH_DIM, out_f64);
+}
+
+int lbh_embed_batch_dim(lbh_ctx* c, const uint8_t* utf8, const int64_t* offsets, int64_t n, int dim, double* out_f64) {
     if (!c || n < 0 || (n > 0 && (!offsets || !out_f64))) return fail(LBH_E_INVALID, "bad argument");
+    if (dim < 1 || dim > LBH_DIM) return fail(LBH_E_INVALID, "dim must be in 1..64 (a token only has 64 digest bytes, lb/latent.py:49-52)");
     if (n == 0) return LBH_OK;
     const int64_t base = offsets[0], bytes = offsets[n] - base;
     if (bytes < 0 || (bytes > 0 && !utf8)) return fail(LBH_E_INVALID, "bad offsets");
@@ -480,7 +498,7 @@ int lbh_embed_batch(lbh_ctx* c, const uint8_t* utf8, const int64_t* offsets, int
     }
     if (bytes > 0) HIP_TRY(hipMemcpyAsync(c->d_text, utf8 + base, (size_t)bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_off, offp, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(lbh_launch_embed(c->d_text, c->d_off, n, c->d_vec, nullptr, s));
+    HIP_TRY(lbh_launch_embed(c->d_text, c->d_off, n, c->d_vec, nullptr, s, dim));
     HIP_TRY(hipMemcpyAsync(out_f64, c->d_vec, (size_t)n * 64 * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return LBH_OK;
@@ -563,6 +581,7 @@ int lbh_index_destroy(lbh_index* ix) {
     if (w.bq_result_host) (void)hipHostFree(w.bq_result_host);
     if (w.rc_result_host) (void)hipHostFree(w.rc_result_host);
     if (ix->staging) (void)hipHostFree(ix->staging);
+    if (ix->dscratch) (void)hipFree(ix->dscratch);
     delete ix;
     return LBH_OK;
 }
@@ -666,6 +685,91 @@ int lbh_index_retract(lbh_index* ix, uint64_t id) {
     return LBH_OK;
 }
 
+int lbh_index_retract_many(lbh_index* ix, int64_t n, const uint64_t* ids) {
+    if (!ix || n < 0 || (n > 0 && !ids)) return fail(LBH_E_INVALID, "bad argument");
+    if (n == 0) return LBH_OK;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    // rows to delete, ascending; an unknown or repeated id fails the whole call before anything changes
+    std::vector<int64_t> dead((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (ids[i] >= ix->row_of_id.size() || ix->row_of_id[(size_t)ids[i]] < 0)
+            return fail(LBH_E_NOTFOUND, "unknown claim id %llu", (unsigned long long)ids[i]);
+        dead[(size_t)i] = ix->row_of_id[(size_t)ids[i]];
+    }
+    std::sort(dead.begin(), dead.end());
+    for (int64_t i = 1; i < n; ++i)
+        if (dead[(size_t)i] == dead[(size_t)i - 1]) return fail(LBH_E_INVALID, "a claim id appears twice in the batch");
+    lbh_ctx* c = ix->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int64_t n_old = ix->n, n_new = n_old - n;
+    // holes = deleted rows below the new end; movers = surviving rows at or above it (as many as holes)
+    const int64_t n_holes = std::lower_bound(dead.begin(), dead.end(), n_new) - dead.begin();
+    int rc = ensure_staging(ix, std::max<int64_t>(n_holes, 1) * 16);
+    if (rc) return rc;
+    int64_t* pairs = reinterpret_cast<int64_t*>(ix->staging);
+    {
+        int64_t np = 0;
+        size_t di = (size_t)n_holes;  // first deleted row in the tail
+        for (int64_t r = n_new; r < n_old && np < n_holes; ++r) {
+            if (di < dead.size() && dead[di] == r) { ++di; continue; }
+            pairs[2 * np] = dead[(size_t)np];
+            pairs[2 * np + 1] = r;
+            ++np;
+        }
+        if (np != n_holes) return fail(LBH_E_INTERNAL, "retract_many: %lld movers for %lld holes", (long long)np, (long long)n_holes);
+    }
+    if (n_holes > 0) {
+        if (ix->emb16 && ix->emb16_rows < ix->n) {  // bring the fp16 copy up to date so that it can follow the moves
+            rc = ensure_emb16(ix);
+            if (rc) return rc;
+        }
+        rc = ensure_dscratch(ix, n_holes * 16);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->dscratch, pairs, (size_t)n_holes * 16, hipMemcpyHostToDevice, s));
+        HIP_TRY(lbh_launch_move_rows(ix->emb32, ix->emb64, (ix->emb16 && ix->emb16_rows == ix->n) ? ix->emb16 : nullptr, ix->created,
+                                     ix->tags, ix->keys, ix->order, reinterpret_cast<const int64_t*>(ix->dscratch), n_holes, s));
+        HIP_TRY(hipStreamSynchronize(s));  // the staging area is reused by the next call
+    }
+    for (int64_t i = 0; i < n; ++i) ix->row_of_id[(size_t)ids[i]] = -1;
+    for (int64_t p = 0; p < n_holes; ++p) {
+        const uint64_t moved = ix->id_of_row[(size_t)pairs[2 * p + 1]];
+        ix->id_of_row[(size_t)pairs[2 * p]] = moved;
+        ix->row_of_id[(size_t)moved] = pairs[2 * p];
+    }
+    ix->id_of_row.resize((size_t)n_new);
+    if (ix->emb16_rows == n_old) ix->emb16_rows = n_new;  // the copy followed the moves
+    else ix->emb16_rows = std::min(ix->emb16_rows, n_new);  // only reached without moves: the converted prefix stays valid
+    ix->n = n_new;
+    return LBH_OK;
+}
+
+int lbh_index_get_embeddings(lbh_index* ix, int64_t n, const uint64_t* ids, double* out_f64) {
+    if (!ix || n < 0 || (n > 0 && (!ids || !out_f64))) return fail(LBH_E_INVALID, "bad argument");
+    if (n == 0) return LBH_OK;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIP_TRY(hipSetDevice(ix->ctx->device));
+    hipStream_t s = ix->ctx->stream;
+    int rc = ensure_staging(ix, n * 8);
+    if (rc) return rc;
+    int64_t* rows = reinterpret_cast<int64_t*>(ix->staging);
+    for (int64_t i = 0; i < n; ++i) {
+        if (ids[i] >= ix->row_of_id.size() || ix->row_of_id[(size_t)ids[i]] < 0)
+            return fail(LBH_E_NOTFOUND, "unknown claim id %llu", (unsigned long long)ids[i]);
+        rows[i] = ix->row_of_id[(size_t)ids[i]];
+    }
+    const int64_t rows_bytes = (n * 8 + 511) / 512 * 512;
+    rc = ensure_dscratch(ix, rows_bytes + n * 512);
+    if (rc) return rc;
+    int64_t* d_rows = reinterpret_cast<int64_t*>(ix->dscratch);
+    double* d_out = reinterpret_cast<double*>(reinterpret_cast<char*>(ix->dscratch) + rows_bytes);
+    HIP_TRY(hipMemcpyAsync(d_rows, rows, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(lbh_launch_gather_rows_f64(ix->emb64, d_rows, n, d_out, s));
+    HIP_TRY(hipMemcpyAsync(out_f64, d_out, (size_t)n * 512, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return LBH_OK;
+}
+
 int lbh_index_update_meta(lbh_index* ix, uint64_t id, int64_t created_ms, uint64_t tagmask, const uint8_t* hashkey) {
     if (!ix || !hashkey) return fail(LBH_E_INVALID, "bad argument");
     std::lock_guard<std::mutex> lk(ix->mu);
@@ -719,14 +823,12 @@ int lbh_index_set_order(lbh_index* ix, int64_t n, const uint64_t* ids, const uin
         h_rows[i] = ix->row_of_id[(size_t)ids[i]];
         h_vals[i] = order[i];
     }
-    void* d = nullptr;
-    HIP_TRY(hipMalloc(&d, (size_t)n * 16));
-    hipError_t e = hipMemcpyAsync(d, ix->staging, (size_t)n * 16, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess)
-        e = lbh_launch_scatter_u64(ix->order, reinterpret_cast<const int64_t*>(d), reinterpret_cast<const uint64_t*>(d) + n, n, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d);
-    HIP_TRY(e);
+    rc = ensure_dscratch(ix, n * 16);
+    if (rc) return rc;
+    void* d = ix->dscratch;
+    HIP_TRY(hipMemcpyAsync(d, ix->staging, (size_t)n * 16, hipMemcpyHostToDevice, s));
+    HIP_TRY(lbh_launch_scatter_u64(ix->order, reinterpret_cast<const int64_t*>(d), reinterpret_cast<const uint64_t*>(d) + n, n, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return LBH_OK;
 }
 

@@ -101,7 +101,7 @@ constexpr int EMB_HEAD = 128;  // bytes of every claim fetched up front (one rou
 __global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __restrict__ utf8,
                                                                 const int64_t* __restrict__ offsets, int64_t n,
                                                                 double* __restrict__ out64,
-                                                                float* __restrict__ out32) {
+                                                                float* __restrict__ out32, int dim) {
     __shared__ double lut[256];
     __shared__ int tok_start[EMB_WAVES][TOK_RING];
     __shared__ int tok_end[EMB_WAVES][TOK_RING];
@@ -282,14 +282,22 @@ __global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __
         for (int c = 0; c < EMB_GROUP; ++c) {
             if (c < gn) {
                 double ss = 0.0;
+                if (dim == 64) {
 #pragma unroll
-                for (int d = 0; d < 64; ++d) {
-                    const double x = readlane_f64(acc[c], d);
-                    ss = ss + x * x;
+                    for (int d = 0; d < 64; ++d) {
+                        const double x = readlane_f64(acc[c], d);
+                        ss = ss + x * x;
+                    }
+                } else {  // embed(text, dim) with dim < 64: the norm runs over the first `dim` components only (:54)
+#pragma unroll
+                    for (int d = 0; d < 64; ++d) {
+                        const double x = readlane_f64(acc[c], d);
+                        if (d < dim) ss = ss + x * x;
+                    }
                 }
                 const double nrm = __builtin_sqrt(ss);
                 double o = 0.0;
-                if (((has_tok >> c) & 1u) && nrm != 0.0) o = acc[c] / nrm;
+                if (((has_tok >> c) & 1u) && nrm != 0.0 && lane < dim) o = acc[c] / nrm;
                 out64[(g0 + c) * 64 + lane] = o;
                 if (out32) out32[(g0 + c) * 64 + lane] = (float)o;
             }
@@ -339,6 +347,31 @@ __global__ void move_row_kernel(float* emb32, double* emb64, uint16_t* emb16, in
     if (l == 6) order[dst] = order[src];
 }
 
+// batched swap-delete (lbh_index_retract_many): pair p copies row pairs[2p+1] (a survivor from the tail that is cut
+// off) over row pairs[2p] (a hole below the new end).  Sources and destinations are disjoint, so pairs are independent.
+__global__ void move_rows_kernel(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
+                                 uint64_t* order, const int64_t* __restrict__ pairs, int64_t n_pairs) {
+    const int l = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= n_pairs) return;
+    const int64_t dst = pairs[2 * p], src = pairs[2 * p + 1];
+    emb32[dst * 64 + l] = emb32[src * 64 + l];
+    if (emb16) emb16[dst * 64 + l] = emb16[src * 64 + l];
+    emb64[dst * 64 + l] = emb64[src * 64 + l];
+    if (l < 4) keys[dst * 4 + l] = keys[src * 4 + l];
+    if (l == 4) created[dst] = created[src];
+    if (l == 5) tags[dst] = tags[src];
+    if (l == 6) order[dst] = order[src];
+}
+
+// out[i] = emb64 row rows[i] (batched _embedding_cache reads)
+__global__ void gather_rows_f64_kernel(const double* __restrict__ emb64, const int64_t* __restrict__ rows, int64_t n,
+                                       double* __restrict__ out) {
+    const int l = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i < n) out[i * 64 + l] = emb64[rows[i] * 64 + l];
+}
+
 // order[r0 + i] = first + i: rows appended without an explicit order sort by insertion
 __global__ void iota_u64_kernel(uint64_t* dst, uint64_t first, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -354,11 +387,11 @@ __global__ void scatter_u64_kernel(uint64_t* dst, const int64_t* __restrict__ ro
 }  // namespace
 
 hipError_t lbh_launch_embed(const uint8_t* utf8_dev, const int64_t* offsets_dev, int64_t n, double* out64_dev,
-                            float* out32_dev, hipStream_t s) {
+                            float* out32_dev, hipStream_t s, int dim) {
     if (n <= 0) return hipSuccess;
     int64_t blocks = (n + EMB_WAVES * EMB_GROUP - 1) / (EMB_WAVES * EMB_GROUP);
     if (blocks > 256 * 32) blocks = 256 * 32;
-    embed_kernel<<<dim3((unsigned)blocks), dim3(EMB_WAVES * 64), 0, s>>>(utf8_dev, offsets_dev, n, out64_dev, out32_dev);
+    embed_kernel<<<dim3((unsigned)blocks), dim3(EMB_WAVES * 64), 0, s>>>(utf8_dev, offsets_dev, n, out64_dev, out32_dev, dim);
     return hipGetLastError();
 }
 
@@ -378,6 +411,19 @@ hipError_t lbh_launch_f64_to_f32(const double* in_dev, float* out_dev, int64_t n
 hipError_t lbh_launch_move_row(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
                                uint64_t* order, int64_t dst, int64_t src, hipStream_t s) {
     move_row_kernel<<<1, 64, 0, s>>>(emb32, emb64, emb16, created, tags, keys, order, dst, src);
+    return hipGetLastError();
+}
+
+hipError_t lbh_launch_move_rows(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
+                                uint64_t* order, const int64_t* pairs_dev, int64_t n_pairs, hipStream_t s) {
+    if (n_pairs <= 0) return hipSuccess;
+    move_rows_kernel<<<dim3((unsigned)((n_pairs + 3) / 4)), 256, 0, s>>>(emb32, emb64, emb16, created, tags, keys, order, pairs_dev, n_pairs);
+    return hipGetLastError();
+}
+
+hipError_t lbh_launch_gather_rows_f64(const double* emb64, const int64_t* rows_dev, int64_t n, double* out_dev, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    gather_rows_f64_kernel<<<dim3((unsigned)((n + 3) / 4)), 256, 0, s>>>(emb64, rows_dev, n, out_dev);
     return hipGetLastError();
 }
 

@@ -127,12 +127,16 @@ struct lbh_workspace {
 
 // ---- kernel launchers (defined in the .hip files) ---------------------------------------------
 // embed.hip
+// dim: LBH_DIM for the index; 1..63 = embed(text, dim) of lb/latent.py:41 (components >= dim are written as 0)
 hipError_t lbh_launch_embed(const uint8_t* utf8_dev, const int64_t* offsets_dev, int64_t n, double* out64_dev,
-                            float* out32_dev, hipStream_t s);
+                            float* out32_dev, hipStream_t s, int dim = LBH_DIM);
 hipError_t lbh_launch_cosine(const double* a_dev, const double* b_dev, int64_t n, double* out_dev, hipStream_t s);
 hipError_t lbh_launch_f64_to_f32(const double* in_dev, float* out_dev, int64_t n_elems, hipStream_t s);
 hipError_t lbh_launch_move_row(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
                                uint64_t* order, int64_t dst, int64_t src, hipStream_t s);
+hipError_t lbh_launch_move_rows(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
+                                uint64_t* order, const int64_t* pairs_dev, int64_t n_pairs, hipStream_t s);
+hipError_t lbh_launch_gather_rows_f64(const double* emb64, const int64_t* rows_dev, int64_t n, double* out_dev, hipStream_t s);
 hipError_t lbh_launch_f64_to_f16(const double* in_dev, uint16_t* out_dev, int64_t n_elems, hipStream_t s);
 hipError_t lbh_launch_iota_u64(uint64_t* dst, uint64_t first, int64_t n, hipStream_t s);
 hipError_t lbh_launch_scatter_u64(uint64_t* dst, const int64_t* rows_dev, const uint64_t* vals_dev, int64_t n, hipStream_t s);
@@ -154,3 +158,4 @@ hipError_t lbh_launch_recent(const int64_t* created, const uint64_t* order, int6
 hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, int nq, int k, int has_since,
                                      int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, float norm_scale, hipStream_t s,
                                      hipEvent_t ev0, hipEvent_t ev1);
+

@@ -1304,7 +1304,10 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_exact_kernel(lbh_dev_in
                                                                        lbh_cursor cur,
                                                                        uint64_t* __restrict__ xc_ord,
                                                                        uint32_t* __restrict__ xc_row,
-                                                                       int32_t* __restrict__ flags) {
+                                                                       int32_t* __restrict__ flags,
+                                                                       const int32_t* __restrict__ gate) {
+    // gate (allocation-free entry point only): run only if the fast path reported an unbounded candidate set
+    if (gate && *gate != 1) return;
     __shared__ uint64_t wo[LBH_SCAN_WAVES][LBH_WCAP];
     __shared__ uint32_t wr[LBH_SCAN_WAVES][LBH_WCAP];
     __shared__ double qs[64];
@@ -1382,12 +1385,14 @@ __global__ __launch_bounds__(SEL_THREADS) void select_exact_kernel(lbh_dev_index
                                                                     const uint64_t* __restrict__ xc_ord,
                                                                     const uint32_t* __restrict__ xc_row,
                                                                     int32_t* __restrict__ flags,
-                                                                    lbh_result* __restrict__ res, int seq) {
+                                                                    lbh_result* __restrict__ res, int seq,
+                                                                    const int32_t* __restrict__ gate) {
     __shared__ uint64_t sbuf[2 * LBH_MCAP];
     __shared__ int hist[256];
     __shared__ int64_t sh_krem;
     __shared__ int sh_bin, sh_cnt, sh_gt, sh_eq;
     const int tid = threadIdx.x;
+    if (gate && *gate != 1) return;  // block-uniform; gate points into *res, which is first written after the barrier below
     if (tid == 0) { sh_cnt = 0; sh_gt = 0; sh_eq = 0; }
     const int E = flags[2];
     __syncthreads();
@@ -1817,7 +1822,7 @@ hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace&
     hipError_t e;
     if (ev0) (void)hipEventRecord(ev0, s);
     const dim3 g(grid), b(LBH_SCAN_THREADS);
-#define LBH_XSCAN_ARGS ix, qptr, qa, k, since_ms, tag_mask, cur, ws.xcand_ord, ws.xcand_row, ws.flags
+#define LBH_XSCAN_ARGS ix, qptr, qa, k, since_ms, tag_mask, cur, ws.xcand_ord, ws.xcand_row, ws.flags, nullptr
     if (has_since && tag_mask) scan_exact_kernel<true, true><<<g, b, 0, s>>>(LBH_XSCAN_ARGS);
     else if (has_since) scan_exact_kernel<true, false><<<g, b, 0, s>>>(LBH_XSCAN_ARGS);
     else if (tag_mask) scan_exact_kernel<false, true><<<g, b, 0, s>>>(LBH_XSCAN_ARGS);
@@ -1826,7 +1831,7 @@ hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace&
     if (ev1) (void)hipEventRecord(ev1, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    select_exact_kernel<<<1, SEL_THREADS, 0, s>>>(ix, k, ws.xcand_ord, ws.xcand_row, ws.flags, ws.result_dev, seq);
+    select_exact_kernel<<<1, SEL_THREADS, 0, s>>>(ix, k, ws.xcand_ord, ws.xcand_row, ws.flags, ws.result_dev, seq, nullptr);
     return hipGetLastError();
 }
 

@@ -25,15 +25,18 @@ def _tokenize(text: str) -> List[str]:
 
 
 def embed(text: str, dim: int = 64) -> List[float]:
-    """lb/latent.py:41-57.  ``dim`` <= 64 truncates the accumulation exactly like the reference
-    (norm over the first ``dim`` components); dim > 64 is the reference's IndexError."""
+    """lb/latent.py:41-57.  ``dim`` < 64 truncates the accumulation exactly like the reference (first ``dim``
+    digest bytes, norm over the first ``dim`` components; computed by the same kernel); dim > 64 is the
+    reference's IndexError once the text has a token; dim <= 0 is its empty list."""
     if dim == _hip.DIM:
         return _hip.embed_batch([text])[0].tolist()
     if dim > _hip.DIM:
         if _tokenize(text):
             raise IndexError("index out of range")  # b[i] with i >= 64, lb/latent.py:52
         return [0.0] * dim
-    raise NotImplementedError("lbm_amd implements the reference's dim=64 (no caller passes another)")
+    if dim <= 0:
+        return [0.0] * dim
+    return _hip.embed_batch([text], dim)[0, :dim].tolist()
 
 
 def embed_many(texts: Sequence[str]) -> np.ndarray:

@@ -141,6 +141,33 @@ static void lut_init(void) {
 
 double lbo_lut(int b) { lut_init(); return LUT[b & 255]; }
 
+/* lb/latent.py:41-57 for 1 <= dim <= 64: only the first `dim` digest bytes are accumulated (:50-52) and the norm runs
+ * over those `dim` components (:54); out receives `dim` doubles.  (dim > 64 is the reference's IndexError and dim = 0
+ * its empty list: the Python front-end answers both.) */
+void lbo_embed_dim(const uint8_t* utf8, int64_t len, int dim, double* out) {
+    lut_init();
+    double v[LBO_DIM];
+    for (int d = 0; d < dim; ++d) v[d] = 0.0;
+    int64_t i = 0, ntok = 0;
+    uint8_t b[64];
+    while (i < len) {
+        while (i < len && !is_word(utf8[i])) ++i;
+        if (i >= len) break;
+        int64_t s = i;
+        while (i < len && is_word(utf8[i])) ++i;
+        sha256_token(utf8 + s, (size_t)(i - s), 0, 1, b);      /* :47 */
+        sha256_token(utf8 + s, (size_t)(i - s), 1, 1, b + 32); /* :48 */
+        for (int d = 0; d < dim; ++d) v[d] += LUT[b[d]];       /* :50-52 */
+        ++ntok;
+    }
+    if (ntok == 0) { for (int d = 0; d < dim; ++d) out[d] = 0.0; return; } /* :43-44 */
+    double acc = 0.0;
+    for (int d = 0; d < dim; ++d) acc = acc + v[d] * v[d]; /* :54 sum(x*x) */
+    double n = sqrt(acc);
+    if (n == 0.0) { for (int d = 0; d < dim; ++d) out[d] = 0.0; return; } /* :55-56 */
+    for (int d = 0; d < dim; ++d) out[d] = v[d] / n; /* :57 */
+}
+
 /* lb/latent.py:41-57 with dim = 64 (the only value any caller uses). */
 void lbo_embed(const uint8_t* utf8, int64_t len, double out[LBO_DIM]) {
     lut_init();

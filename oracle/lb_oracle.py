@@ -55,6 +55,8 @@ def lib() -> ctypes.CDLL:
         L.lbo_lut.restype = ctypes.c_double
         L.lbo_embed.argtypes = [u8p, ctypes.c_int64, f64p]
         L.lbo_embed.restype = None
+        L.lbo_embed_dim.argtypes = [u8p, ctypes.c_int64, ctypes.c_int, f64p]
+        L.lbo_embed_dim.restype = None
         L.lbo_embed_batch.argtypes = [u8p, i64p, ctypes.c_int64, f64p]
         L.lbo_embed_batch.restype = None
         L.lbo_cosine.argtypes = [f64p, ctypes.c_int64, f64p, ctypes.c_int64, f64p]
@@ -113,10 +115,21 @@ def embed_array(text: str) -> np.ndarray:
 
 
 def embed(text: str, dim: int = DIM) -> List[float]:
-    """lb/latent.py:41-57.  Only dim == 64 is restated (no caller passes another)."""
-    if dim != DIM:
-        raise NotImplementedError("oracle restates dim=64 only")
-    return embed_array(text).tolist()
+    """lb/latent.py:41-57, any dim: the first `dim` digest bytes, norm over `dim` components; dim > 64 with at
+    least one token is the reference's IndexError (:52 reads b[i] past the 64 digest bytes)."""
+    if dim == DIM:
+        return embed_array(text).tolist()
+    if dim > DIM:
+        if tokenize(text):
+            raise IndexError("index out of range")
+        return [0.0] * dim
+    if dim <= 0:
+        return []  # [0.0] * dim; with tokens the loops over range(dim) do nothing and the norm of [] is 0.0
+    b = text.encode("utf-8", "surrogatepass")
+    a = _bytes_arr(b)
+    out = np.zeros(dim, dtype=np.float64)
+    lib().lbo_embed_dim(_u8(a), len(b), int(dim), _f64(out))
+    return out.tolist()
 
 
 def pack_texts(texts: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
@@ -212,6 +225,30 @@ class OracleGraph:
         if c:
             c.retracted = True
             self._embedding_cache.pop(claim_hash, None)  # :89
+
+    def snapshot(self) -> Dict[str, object]:
+        """lb/context_graph.py:135-137 (+ Claim.to_dict, :20-31: parent_hash only when set)."""
+        out = {}
+        for h, c in self.claims.items():
+            d = {"claim_hash": c.claim_hash, "text": c.text, "tags": list(c.tags), "created_ms": int(c.created_ms),
+                 "evidence": list(c.evidence), "retracted": bool(c.retracted)}
+            if c.parent_hash is not None:
+                d["parent_hash"] = c.parent_hash
+            out[h] = d
+        return {"claims": out}
+
+    @staticmethod
+    def from_snapshot(s: Dict[str, object]) -> "OracleGraph":
+        """lb/context_graph.py:139-148: every non-retracted claim is re-embedded from its text."""
+        g = OracleGraph()
+        for h, cd in (s.get("claims", {}) or {}).items():
+            c = OracleClaim(str(cd["claim_hash"]), str(cd.get("text", "")), list(cd.get("tags", [])),
+                            int(cd.get("created_ms", 0)), list(cd.get("evidence", [])), cd.get("parent_hash"),
+                            bool(cd.get("retracted", False)))
+            g.claims[h] = c
+            if not c.retracted:
+                g._embedding_cache[h] = embed_array(c.text)
+        return g
 
     def compile(self, query: str, *, top_k: int = 8, since_ms: Optional[int] = None,
                 tags: Optional[Sequence[str]] = None) -> Tuple[str, List[str]]:

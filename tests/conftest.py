@@ -33,3 +33,13 @@ def golden_compile():
 @pytest.fixture(scope="session")
 def golden_synth():
     return load_golden("synth2k.json")["data"]
+
+
+@pytest.fixture(scope="session")
+def golden_snapshot():
+    return load_golden("snapshot.json")["data"]
+
+
+@pytest.fixture(scope="session")
+def golden_embed_dim():
+    return load_golden("embed_dim.json")["data"]

@@ -48,8 +48,9 @@ def corpus():
             half[r].add_vectors(v[r::2], ms[r::2], tags[r::2], keys[r::2])
         if s == 0:
             keep_vec, keep_key, keep_ms, keep_tags = v.copy(), keys.copy(), ms.copy(), tags.copy()
-    q = rng.standard_normal((40, 64))
+    q = rng.standard_normal((256, 64))  # a full K3 launch: all eight query groups of every workgroup are in use
     q[:8] = keep_vec[[5, 17, 1000, 1001, 4242, 99_999, 500_000, 999_999]] + 0.05 * rng.standard_normal((8, 64))
+    q[40:168] = centres[rng.integers(0, 256, size=128)] + 0.2 * rng.standard_normal((128, 64))  # near the last chunk's clusters
     q /= np.linalg.norm(q, axis=1, keepdims=True)
     yield {"hip": hip, "ix": ix, "half": half, "q": q, "vec0": keep_vec, "key0": keep_key, "ms0": keep_ms, "tags0": keep_tags}
     ix.close()
@@ -79,10 +80,13 @@ def test_fast_vs_exact_vs_batched_10m(corpus):
     for mode in (0, 1):
         assert batched[mode][0].tolist() == batched[2][0].tolist() and batched[mode][1].tobytes() == batched[2][1].tobytes()
     bi, bs, bc = batched[2]
+    assert q.shape[0] == 256
     for j in range(q.shape[0]):
         i8, s8, _ = ix.search_shard(q[j], 8, hip.SINCE_NONE, 0, st)
         assert st.path == 0 and st.fallbacks == 0
         assert bi[j, : int(bc[j])].tolist() == i8.tolist() and bs[j, : int(bc[j])].tobytes() == s8.tobytes()
+        if j >= 40:
+            continue
         again, s_again, _ = ix.search_shard(q[j], 8, hip.SINCE_NONE, 0)
         assert again.tolist() == i8.tolist() and s_again.tobytes() == s8.tobytes()  # idempotent
         hip.set_option("scan_mode", 1)  # the fp16 copy of the matrix as scan operand: same answer, half the bytes
@@ -97,6 +101,21 @@ def test_fast_vs_exact_vs_batched_10m(corpus):
             assert i64[:8].tolist() == i8.tolist() and i200[:64].tolist() == i64.tolist()
             assert s200[:64].tobytes() == s64.tobytes() and len(i200) == 200
             _check_order(hip, ix, q[j], i64, s64)
+
+
+def test_batched_256_filters_and_k16_10m(corpus):
+    """Config 3 at full width with the fused masks: 256 queries x 10 M claims, since / tag filters, top-16; every
+    query equals the single-query path (which test_first_million_against_oracle ties to the oracle)."""
+    hip, ix, q = corpus["hip"], corpus["ix"], corpus["q"]
+    st = hip.Stats()
+    p50 = 1_700_000_000_000 + 1000 * (N_FULL // 2)
+    for k, since, tm in ((16, hip.SINCE_NONE, 0), (8, p50, 0), (8, hip.SINCE_NONE, 0xF0F0), (16, p50, 0x0F0F)):
+        bi, bs, bc = ix.search(q, k, since, tm, st)
+        assert st.path == 2 and st.bytes_per_row in (128 + 8 * (since != hip.SINCE_NONE) + 8 * (tm != 0),
+                                                      256 + 8 * (since != hip.SINCE_NONE) + 8 * (tm != 0))
+        for j in range(0, 256, 3):
+            wi, ws, _ = ix.search_shard(q[j], k, since, tm)
+            assert bi[j, : int(bc[j])].tolist() == wi.tolist() and bs[j, : int(bc[j])].tobytes() == ws.tobytes(), (k, since, tm, j)
 
 
 def test_exact_path_equals_fast_path_10m(corpus):
@@ -143,15 +162,71 @@ def test_first_million_against_oracle(corpus):
     ix = hip.Index()
     ix.add_vectors(v, ms, tags, keys)
     packed = orc.pack_texts([bytes(k).hex() for k in keys])
-    bi, bs, bc = ix.search(q[:12], 8, hip.SINCE_NONE, 0)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(16) as ex:  # the oracle on 16 host threads: 256 queries x 1 M claims
+        want = list(ex.map(lambda j: orc.compile_arrays(v, ms, None, None, q[j], 8, None, packed_keys=packed), range(256)))
+    for mode in (2, 1, 0):  # every K3 precision, all 256 queries in ONE search call
+        hip.set_option("bq_mode", mode)
+        bi, bs, bc = ix.search(q, 8, hip.SINCE_NONE, 0)
+        for j in range(256):
+            want_i, want_s = want[j]
+            assert bi[j, : int(bc[j])].tolist() == want_i.tolist() and bs[j, : int(bc[j])].tobytes() == want_s.tobytes(), (mode, j)
+    hip.set_option("bq_mode", 2)
     for j in range(12):
-        want_i, want_s = orc.compile_arrays(v, ms, None, None, q[j], 8, None, packed_keys=packed)
+        want_i, want_s = want[j]
         got_i, got_s, _ = ix.search_shard(q[j], 8, hip.SINCE_NONE, 0)
         assert got_i.tolist() == want_i.tolist() and got_s.tobytes() == want_s.tobytes()
-        assert bi[j, : int(bc[j])].tolist() == want_i.tolist() and bs[j, : int(bc[j])].tobytes() == want_s.tobytes()
     want_i, want_s = orc.compile_arrays(v, ms, None, None, q[0], 64, int(ms[600_000]), tags, 0xFF, packed_keys=packed)
     got_i, got_s, _ = ix.search_shard(q[0], 64, int(ms[600_000]), 0xFF)
     assert got_i.tolist() == want_i.tolist() and got_s.tobytes() == want_s.tobytes()
+    ix.close()
+
+
+def test_text_path_10m_k1_sampled_against_oracle():
+    """Config 5 at bench scale through the TEXT path: 10 M synthetic claims are vectorised by K1 (lbh_index_add with
+    texts, exactly what bench.py does), 1 % leave again through lbh_index_retract_many, and 2 000 random rows per chunk
+    (20 000 in all) are read back and compared bit for bit with the oracle's embedding of the same text.  Then the
+    ranking over that corpus is tied to the oracle through the sample: the k winners' scores are the oracle's dot
+    products of the oracle's embeddings."""
+    from lbm_amd import _hip as hip, synth
+    rng = np.random.default_rng(77)
+    ix = hip.Index()
+    ix.reserve(N_FULL)
+    kept = {}
+    for ci in range(N_FULL // 1_000_000):
+        ch = synth.make_chunk(ci * 1_000_000, 1_000_000, seed=1234, chunk_index=ci, real_sha_keys=False)
+        ids = ix.add_texts(ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)
+        assert int(ids[0]) == ci * 1_000_000 and int(ids[-1]) == (ci + 1) * 1_000_000 - 1
+        ix.retract_many(ids[ch.retracted])
+        pick = rng.choice(np.nonzero(~ch.retracted)[0], size=2000, replace=False)
+        pick[:4] = np.nonzero(~ch.retracted)[0][[0, 1, -2, -1]]  # chunk edges: first / last K1 groups of the launch
+        want = orc.embed_batch([ch.text(int(i)) for i in pick])
+        got = ix.get_embeddings(ids[pick])
+        assert got.tobytes() == want.tobytes(), ci
+        if ci in (0, 9):
+            kept[ci] = (ch, ids)
+    live = ix.size()
+    assert N_FULL * 0.985 < live < N_FULL * 0.995
+    st = hip.Stats()
+    queries = synth.make_queries(6, seed=4321) + [kept[0][0].text(12345), kept[9][0].text(999_000)]
+    qv = hip.embed_batch(queries)
+    assert qv.tobytes() == orc.embed_batch(queries).tobytes()
+    for j, q in enumerate(qv):
+        i8, s8, _ = ix.search_shard(q, 8, hip.SINCE_NONE, 0, st)
+        assert st.path == 0 and st.rows_scanned == live
+        i200, s200, _ = ix.search_shard(q, 200, hip.SINCE_NONE, 0)  # pages 2.. come from the exact fp64 scan
+        assert i200[:8].tolist() == i8.tolist() and s200[:8].tobytes() == s8.tobytes()
+        vecs = ix.get_embeddings(i8)
+        assert [orc.cosine(q, vecs[r]) for r in range(8)] == s8.tolist()
+    # the two claims whose own text is the query must come first (or tie with an exact duplicate of that text)
+    for ci, local in ((0, 12345), (9, 999_000)):
+        ch, ids = kept[ci]
+        if ch.retracted[local]:
+            continue
+        q = hip.embed_batch([ch.text(local)])[0]
+        i8, s8, _ = ix.search_shard(q, 8, hip.SINCE_NONE, 0)
+        top = i8[s8 == s8[0]].tolist()
+        assert int(ids[local]) in top
     ix.close()
 
 

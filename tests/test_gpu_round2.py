@@ -1,0 +1,226 @@
+"""Round-2 GPU parity tests: snapshot reload against vectors from the reference, embed(text, dim < 64), the batched
+tombstone path (lbh_index_retract_many) and the host mirror's failure handling.  Bit-exact, through the C ABI."""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+from oracle import lb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from lbm_amd import _hip
+    assert "gfx950" in _hip.device_name()
+    return _hip
+
+
+def hexes(v):
+    return [float(x).hex() for x in v]
+
+
+def test_embed_dim_golden(hip, golden_embed_dim):
+    """lb/latent.py:41-57 with dim != 64, against the reference's own outputs."""
+    from lbm_amd.latent import embed
+    for c in golden_embed_dim["cases"] + golden_embed_dim["special"]:
+        got = embed(c["text"], c["dim"])
+        assert isinstance(got, list) and len(got) == c["dim"]
+        assert hexes(got) == c["embedding"], (c["text"][:20], c["dim"])
+    for c in golden_embed_dim["errors"]:
+        with pytest.raises(IndexError):
+            embed(c["text"], c["dim"])
+    # batched, against the oracle, ragged texts x every dim
+    rng = np.random.default_rng(3)
+    texts = ["".join(rng.choice(list("abcXYZ019_ -.é"), size=int(rng.integers(0, 200)))) for _ in range(300)]
+    for dim in (1, 7, 32, 63):
+        got = hip.embed_batch(texts, dim)
+        assert np.all(got[:, dim:] == 0.0)
+        for i in range(0, len(texts), 7):
+            assert hexes(got[i, :dim]) == hexes(orc.embed(texts[i], dim)), (i, dim)
+
+
+def _replay(ops):
+    from lbm_amd.context_graph import Claim, ContextGraph
+    g = ContextGraph()
+    for op in ops:
+        if op[0] == "add":
+            g.add_claim(op[1], op[2], op[3], created_ms=op[4], parent_hash=op[5] if len(op) > 5 else None)
+        elif op[0] == "retract":
+            g.retract(op[1])
+        elif op[0] == "raw_insert":
+            g.claims[op[1]] = Claim(claim_hash=op[1], text=op[2], tags=list(op[3]), created_ms=op[4], evidence=[])
+        elif op[0] == "flag":
+            g.claims[op[1]].retracted = op[2]
+    return g
+
+
+def test_snapshot_reload_golden_small(hip, golden_snapshot):
+    """snapshot() of a graph with overwritten / retracted / re-added / raw-inserted / hand-flagged claims equals the
+    reference's dict; from_snapshot(reference dict) -> compile equals the reference's reloaded graph (:135-148)."""
+    from lbm_amd.context_graph import ContextGraph
+    case = golden_snapshot[0]
+    for interleave in (False, True):
+        g = _replay(case["ops"])
+        if interleave:
+            g.compile("beta")  # the mirror has been on the device before the snapshot is taken
+        assert g.snapshot() == case["snapshot"]
+    g2 = ContextGraph.from_snapshot(json.loads(json.dumps(case["snapshot"])))
+    assert sorted(g2._embedding_cache) == case["cached_after_load"]
+    for r in case["results"]:
+        kw = {k: r[k] for k in ("top_k", "since_ms") if k in r}
+        assert g2.compile(r["query"], **kw) == (r["context"], r["hashes"]), (r["query"], kw)
+        assert hexes(g2.compile_scored(r["query"], **kw)[1]) == r["scores"]
+    # a reloaded graph keeps working as a live graph
+    og = orc.OracleGraph.from_snapshot(case["snapshot"])
+    for gg in (g2, og):
+        gg.retract("k1")
+        gg.add_claim("k7", "beta epsilon gamma", ["n"], created_ms=90)
+        gg.claims["k5"].retracted = False
+    for q in ("beta", "epsilon", ""):
+        assert g2.compile(q, top_k=10) == og.compile(q, top_k=10)
+
+
+def test_snapshot_reload_golden_synth2k(hip, golden_snapshot, golden_synth):
+    from lbm_amd.context_graph import ContextGraph
+    case, d = golden_snapshot[1], golden_synth
+    n = case["n"]
+    g = ContextGraph()
+    for i in range(n):
+        tags = ["t%02d" % j for j in range(64) if (d["tagmask"][i] >> j) & 1]
+        g.add_claim(d["hashes"][i], d["texts"][i], tags, created_ms=d["created_ms"][i])
+    g.compile("w00001")  # everything on the device first: the overwrites and retracts below hit live rows
+    for i in range(n):
+        if d["retracted"][i]:
+            g.retract(d["hashes"][i])
+    for i in case["overwrite"]:
+        g.add_claim(d["hashes"][i], d["texts"][(i * 7 + 1) % n], ["over"], created_ms=d["created_ms"][i] + 5)
+    for i in case["retract_extra"]:
+        g.retract(d["hashes"][i])
+    snap = g.snapshot()
+    assert hashlib.sha256(json.dumps(snap, sort_keys=True).encode()).hexdigest() == case["snapshot_sha256"]
+    for graph in (g, ContextGraph.from_snapshot(json.loads(json.dumps(snap)))):
+        assert len(graph._embedding_cache) == case["n_cached_after_load"]
+        for r in case["results"]:
+            kw = {k: r[k] for k in ("top_k", "since_ms") if k in r}
+            text, hs = graph.compile(r["query"], **kw)
+            assert hs == r["hashes"], (r["query"], kw)
+            assert hashlib.sha256(text.encode()).hexdigest() == r["context_sha256"]
+            assert hexes(graph.compile_scored(r["query"], **kw)[1]) == r["scores"]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_retract_many_vs_oracle(hip, seed):
+    """C-ABI level: random batches leave the index in one compaction each; searches, recency queries and cached
+    vectors must match the oracle on the surviving claims after every batch, in both scan modes."""
+    rng = np.random.default_rng(seed)
+    n = 20_000
+    v = rng.standard_normal((n, 64))
+    v[1::50] = v[0::50][: v[1::50].shape[0]]
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    ms = rng.integers(0, 5000, size=n).astype(np.int64)
+    tags = rng.integers(0, 2 ** 63, size=n).astype(np.uint64)
+    keys = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    packed = orc.pack_texts([bytes(k).hex() for k in keys])
+    ix = hip.Index()
+    ids = ix.add_vectors(v, ms, tags, keys)
+    dead = np.zeros(n, dtype=np.uint8)
+    qs = rng.standard_normal((6, 64))
+    qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+    hip.set_option("scan_mode", seed % 2)
+    try:
+        for batch in (1, 7, 500, 3000, 1, 9000, 64):
+            alive = np.nonzero(dead == 0)[0]
+            if batch == 9000:  # the whole tail and more: few movers, many tail deletions
+                pick = alive[-batch:]
+            else:
+                pick = rng.choice(alive, size=min(batch, alive.shape[0]), replace=False)
+            ix.retract_many(ids[pick])
+            dead[pick] = 1
+            assert ix.size() == int((dead == 0).sum())
+            for q in qs[:3]:
+                for k, since, tm in ((8, None, 0), (64, 2500, 0), (8, None, 0xFF00)):
+                    wi, ws = orc.compile_arrays(v, ms, dead, None, q, k, since, tags, tm, packed_keys=packed)
+                    gi, gs, _ = ix.search_shard(q, k, hip.SINCE_NONE if since is None else since, tm)
+                    assert gi.tolist() == wi.tolist() and gs.tobytes() == ws.tobytes(), (batch, k, since, tm)
+            bi, bs, bc = ix.search(qs, 8)
+            for j in range(qs.shape[0]):
+                wi, ws = orc.compile_arrays(v, ms, dead, None, qs[j], 8, None, packed_keys=packed)
+                assert bi[j, : int(bc[j])].tolist() == wi.tolist() and bs[j, : int(bc[j])].tobytes() == ws.tobytes()
+            alive = np.nonzero(dead == 0)[0]
+            sample = rng.choice(alive, size=200, replace=False)
+            assert ix.get_embeddings(ids[sample]).tobytes() == v[sample].tobytes()
+            rid, rcreated, matched = ix.recent(1000, 50)
+            want = orc.recent_arrays(np.where(dead == 0, ms, -1), np.arange(n), 1000, 50)
+            assert rid.tolist() == want.tolist() and matched == int(((dead == 0) & (ms >= 1000)).sum())
+        with pytest.raises(hip.HipBackendError, match="unknown claim id"):
+            ix.retract_many(ids[np.nonzero(dead)[0][:1]])
+        alive = np.nonzero(dead == 0)[0]
+        with pytest.raises(hip.HipBackendError, match="twice"):
+            ix.retract_many(ids[[alive[0], alive[1], alive[0]]])
+        assert ix.size() == alive.shape[0]  # failed calls change nothing
+        ix.retract_many(ids[alive])  # everything
+        assert ix.size() == 0 and ix.search_shard(qs[0], 8)[0].shape[0] == 0
+    finally:
+        hip.set_option("scan_mode", 0)
+        ix.close()
+
+
+def test_failed_device_call_keeps_the_mirror_consistent(hip, monkeypatch):
+    """a failing add must not lose claims.  The first add_texts of a sync is made to fail; the next
+    compile must retry and see every claim, parked vectors included."""
+    from lbm_amd.context_graph import ContextGraph
+    g, og = ContextGraph(), orc.OracleGraph()
+    for gg in (g, og):
+        for i in range(50):
+            gg.add_claim("h%02d" % i, "alpha beta w%d" % (i % 7), ["t"], created_ms=i)
+    assert g.compile("alpha w3", top_k=5) == og.compile("alpha w3", top_k=5)
+    for gg in (g, og):
+        gg.claims["h03"].retracted = True      # parked by the next sync
+        gg.retract("h04")
+        gg.add_claim("n1", "alpha gamma", [], created_ms=100)
+        gg.add_claim("n2", "beta w3", [], created_ms=101)
+        gg.add_claim("h05", "overwritten w3 w3", [], created_ms=102)
+    real = hip.Index.add_texts
+    calls = {"n": 0}
+
+    def flaky(self, *a, **kw):
+        calls["n"] += 1
+        if calls["n"] == 1:
+            raise hip.HipBackendError("injected failure")
+        return real(self, *a, **kw)
+
+    monkeypatch.setattr(hip.Index, "add_texts", flaky)
+    with pytest.raises(hip.HipBackendError, match="injected"):
+        g.compile("alpha w3", top_k=5)
+    for q in ("alpha w3", "beta", "gamma", ""):
+        assert g.compile(q, top_k=60) == og.compile(q, top_k=60)
+    for gg in (g, og):
+        gg.claims["h03"].retracted = False     # comes back from its parked vector
+    assert g.compile("alpha w3", top_k=60) == og.compile("alpha w3", top_k=60)
+    with pytest.raises(ValueError, match="finite"):
+        g._embedding_cache["h01"] = [float("nan")] * 64
+    with pytest.raises(ValueError, match="finite"):
+        g._embedding_cache["h01"] = [1e300] * 64
+    assert g.compile("alpha", top_k=60) == og.compile("alpha", top_k=60)
+
+
+def test_in_place_tag_edits_reach_the_device_mask(hip):
+    """Claim.tags edited in place (append / slice assignment) must update the fused tag mask."""
+    from lbm_amd.context_graph import ContextGraph
+    g, og = ContextGraph(), orc.OracleGraph()
+    for gg in (g, og):
+        gg.add_claim("a1", "alpha beta", ["x"], created_ms=1)
+        gg.add_claim("a2", "alpha gamma", [], created_ms=2)
+        gg.add_claim("a3", "alpha delta", ["y"], created_ms=3)
+    assert g.compile("alpha", tags=["x"]) == og.compile("alpha", tags=["x"])
+    for gg in (g, og):
+        gg.claims["a2"].tags.append("x")
+        gg.claims["a1"].tags[:] = ["z"]
+        gg.claims["a3"].tags.remove("y")
+    for tags in (["x"], ["y"], ["z"], ["x", "z"]):
+        assert g.compile("alpha", tags=tags) == og.compile("alpha", tags=tags), tags
+    assert g.compile("alpha") == og.compile("alpha")
+    assert g.claims["a2"].to_dict()["tags"] == ["x"] and type(g.claims["a2"].to_dict()["tags"]) is list

@@ -105,3 +105,40 @@ def test_compile_synth2k_golden(golden_synth):
         idx, sc = orc.compile_arrays(emb, created, retr, keys, qv, r["top_k"], r["since_ms"])
         assert [keys[i] for i in idx] == r["hashes"], (r["query"], r["top_k"], r["since_ms"])
         assert [float(s).hex() for s in sc] == r["scores"]
+
+
+def test_embed_dim_golden(golden_embed_dim):
+    """embed(text, dim) for dim != 64 (lb/latent.py:41-57): truncated accumulation and norm, [] for 0, IndexError past 64."""
+    for c in golden_embed_dim["cases"] + golden_embed_dim["special"]:
+        assert [float(x).hex() for x in orc.embed(c["text"], c["dim"])] == c["embedding"], (c["text"][:20], c["dim"])
+    for c in golden_embed_dim["errors"]:
+        assert c["raises"] == "IndexError"
+        with pytest.raises(IndexError):
+            orc.embed(c["text"], c["dim"])
+
+
+def _replay_r2(ops):
+    g = orc.OracleGraph()
+    for op in ops:
+        if op[0] == "add":
+            g.add_claim(op[1], op[2], op[3], created_ms=op[4], parent_hash=op[5] if len(op) > 5 else None)
+        elif op[0] == "retract":
+            g.retract(op[1])
+        elif op[0] == "raw_insert":
+            g.claims[op[1]] = orc.OracleClaim(op[1], op[2], op[3], op[4], [])
+        elif op[0] == "flag":
+            g.claims[op[1]].retracted = op[2]
+    return g
+
+
+def test_snapshot_reload_golden(golden_snapshot):
+    """lb/context_graph.py:135-148: the oracle graph rebuilt from the reference's snapshot dict answers like the
+    reference graph rebuilt from it (retracted claims are not embedded, everything else is re-embedded from text)."""
+    case = golden_snapshot[0]
+    g = orc.OracleGraph.from_snapshot(case["snapshot"])
+    assert sorted(g._embedding_cache) == case["cached_after_load"]
+    for r in case["results"]:
+        kw = {k: r[k] for k in ("top_k", "since_ms") if k in r}
+        assert g.compile(r["query"], **kw) == (r["context"], r["hashes"])
+        assert [s.hex() for s in g.compile_scored(r["query"], **kw)[1]] == r["scores"]
+    assert _replay_r2(case["ops"]).snapshot() == case["snapshot"]
