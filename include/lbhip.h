@@ -159,6 +159,26 @@ int lbh_index_search_shard(lbh_index* idx, const double* q_f64, int64_t k, int64
                            uint64_t* out_ids, double* out_scores, uint8_t* out_keys, int64_t* out_count,
                            lbh_stats* stats);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory -- code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc: a variant of lbh_index_search_shard that calls no hipMalloc / hipFree /
+ * allocating routine at all.  The caller owns the claim arrays (device pointers, the index's layout: emb32 = n x 64
+ * floats, exactly (float) of emb64 = n x 64 doubles; created_ms / tagmask = n words, needed only when the filter is
+ * used; keywords = n x 4 uint64, word w = the big-endian value of key bytes 8w..8w+7) and the outputs (device
+ * pointers: out_rows = row indices, out_scores, each k entries; *out_count = number of results, or -1 if more than 2048
+ * rows tie on score AND key).  Everything the kernels need beyond that -- candidate lists, counters, the result block,
+ * LBH_NOALLOC_SCRATCH_BYTES in all -- lives in ONE file-scope `static __device__` array of the library, of which every
+ * GPU holds its own copy for the life of the process.  max_row_norm: an upper bound on the row norms (1.0 for vectors
+ * from lbh_embed_batch); the candidate margin scales with it.  Limits: n <= LBH_NOALLOC_MAX_ROWS, k <= LBH_MAX_PAGE
+ * (larger values are rejected, not paged).  The query travels as a kernel argument; the call enqueues its kernels on
+ * the context's stream and returns after one hipStreamSynchronize.  Calls on one GPU share that GPU's array: they are
+ * serialised per context, and two contexts (or processes' threads) on the same GPU must not overlap such calls. */
+#define LBH_NOALLOC_SCRATCH_BYTES 1445120
+#define LBH_NOALLOC_MAX_ROWS 4294967280LL
+int lbh_search_dev_noalloc(lbh_ctx* ctx, const float* emb32_dev, const double* emb64_dev, const int64_t* created_ms_dev,
+                           const uint64_t* tagmask_dev, const uint64_t* keywords_dev, int64_t n, double max_row_norm,
+                           const double* q_f64, int64_t k, int64_t since_ms, uint64_t tag_mask, int64_t* out_rows_dev,
+                           double* out_scores_dev, int64_t* out_count_dev);
+
 /* Merge step of the claim-sharded search (host code, needs no GPU): `lists` = n_lists blocks of (k + 1) x 6
  * int64, as exchanged by the all-gather -- row 0 word 0 = entry count (<= k), rows 1.. = {fp64 score bits,
  * global claim id, 4 big-endian key words}.  Writes the global top-k entries (6 words each) in the

@@ -33,7 +33,7 @@ EXPORTS = [
     "lbh_index_retract_many", "lbh_index_update_meta", "lbh_index_set_keys", "lbh_index_size", "lbh_index_get_embedding",
     "lbh_index_get_embeddings",
     "lbh_index_search", "lbh_index_search_text", "lbh_index_search_shard",
-    "lbh_index_recent", "lbh_index_set_order", "lbh_merge_topk",
+    "lbh_index_recent", "lbh_index_set_order", "lbh_merge_topk", "lbh_search_dev_noalloc",
 ]
 
 
@@ -134,6 +134,8 @@ def load_library() -> ctypes.CDLL:
         L.lbh_merge_topk.argtypes = [_vp, _i64, _i64, _vp, ctypes.POINTER(_i64)]
         L.lbh_index_search_shard.argtypes = [_vp, _vp, _i64, _i64, _u64, _vp, _vp, _vp, ctypes.POINTER(_i64),
                                              ctypes.POINTER(Stats)]
+        L.lbh_search_dev_noalloc.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, _vp, _i64, _i64, _u64,
+                                             _vp, _vp, _vp]
         for name in EXPORTS:
             if name not in ("lbh_last_error", "lbh_version"):
                 getattr(L, name).restype = ctypes.c_int
@@ -234,6 +236,17 @@ def embed_batch(texts: Sequence[str], dim: int = DIM) -> np.ndarray:
 def embed_batch_dev(utf8_ptr: int, offsets_ptr: int, n: int, total_bytes: int, out64_ptr: int, out32_ptr: int = 0):
     _check(load_library().lbh_embed_batch_dev(context(), utf8_ptr, offsets_ptr, n, total_bytes, out64_ptr,
                                               out32_ptr or None))
+
+
+def search_dev_noalloc(emb32_ptr: int, emb64_ptr: int, created_ptr: int, tags_ptr: int, keywords_ptr: int, n: int,
+                       max_row_norm: float, q: np.ndarray, k: int, since_ms: int, tag_mask: int, out_rows_ptr: int,
+                       out_scores_ptr: int, out_count_ptr: int) -> None:
+    """lbh_search_dev_noalloc: device pointers in and out (e.g. torch tensors' data_ptr()), no allocation inside."""
+    q = np.ascontiguousarray(q, dtype=np.float64).reshape(DIM)
+    _check(load_library().lbh_search_dev_noalloc(context(), emb32_ptr or None, emb64_ptr or None, created_ptr or None,
+                                                 tags_ptr or None, keywords_ptr or None, int(n), float(max_row_norm),
+                                                 _ptr(q), int(k), _since(since_ms), int(tag_mask), out_rows_ptr or None,
+                                                 out_scores_ptr or None, out_count_ptr or None))
 
 
 def cosine(a: np.ndarray, b: np.ndarray) -> float:

@@ -50,6 +50,8 @@ struct lbh_ctx {
     int bq_mode = 2;     // batched scan: 0 = exact fp32 MFMA, 1 = split-bf16 products (3 MFMAs at 16x the fp32 rate),
                          // 2 = one fp16 product (a third of the matrix work, margin 2.2e-3)
     int spin_us = 5000;  // poll the completion ticket this long before blocking in hipStreamSynchronize (0 = always block)
+    void* noalloc_scratch = nullptr;  // THIS device's address of search.hip's file-scope scratch array (lbh_search_dev_noalloc)
+    std::mutex noalloc_mu;            // calls that share the array on one GPU would race: serialised per context
     std::mutex mu;  // serialises use of the scratch below
     // small scratch for embed / cosine calls
     uint8_t* d_text = nullptr;
@@ -435,8 +437,15 @@ int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx) {
     if (const char* e5 = getenv("LBH_SCAN_MODE")) c->scan_mode = atoi(e5) != 0;
     if (const char* e4 = getenv("LBH_BQ_MODE")) c->bq_mode = std::max(0, std::min(2, atoi(e4)));
     if (const char* e3 = getenv("LBH_SPIN_US")) c->spin_us = std::max(0, std::min(1000000, atoi(e3)));
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    hipError_t e0 = hipSetDevice(c->device);
+    if (e0 == hipSuccess) e0 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // with this device current: where ITS copy of the allocation-free entry point's scratch array lives
+    if (e0 == hipSuccess) e0 = lbh_noalloc_init(&c->noalloc_scratch);
+    if (e0 != hipSuccess || !c->noalloc_scratch) {
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(LBH_E_DEVICE, "context set-up on device %d failed: %s", devices[0], hipGetErrorString(e0));
+    }
     *out_ctx = c;
     return LBH_OK;
 }
@@ -1077,6 +1086,41 @@ int lbh_index_search_text(lbh_index* ix, const uint8_t* utf8, int64_t len, int64
         // area is only rewritten under ix->mu after this search's final synchronize
     }
     return search_loaded(ix, k, since_ms, tag_mask, out_ids, out_scores, nullptr, out_count, stats);
+}
+
+int lbh_search_dev_noalloc(lbh_ctx* c, const float* emb32_dev, const double* emb64_dev, const int64_t* created_ms_dev,
+                           const uint64_t* tagmask_dev, const uint64_t* keywords_dev, int64_t n, double max_row_norm,
+                           const double* q_f64, int64_t k, int64_t since_ms, uint64_t tag_mask, int64_t* out_rows_dev,
+                           double* out_scores_dev, int64_t* out_count_dev) {
+    if (!c || !q_f64 || !out_count_dev || n < 0) return fail(LBH_E_INVALID, "bad argument");
+    if (n > LBH_NOALLOC_MAX_ROWS)
+        return fail(LBH_E_INVALID, "lbh_search_dev_noalloc serves at most %lld rows per call (got %lld)", (long long)LBH_NOALLOC_MAX_ROWS, (long long)n);
+    if (k < 0) k = 0;
+    if (k > LBH_MAX_PAGE)
+        return fail(LBH_E_INVALID, "lbh_search_dev_noalloc serves top_k <= %d (got %lld): its fixed scratch holds one result page", LBH_MAX_PAGE, (long long)k);
+    if (n > 0 && (!emb32_dev || !emb64_dev || !keywords_dev)) return fail(LBH_E_INVALID, "the matrix and key arrays are required");
+    if (k > 0 && (!out_rows_dev || !out_scores_dev)) return fail(LBH_E_INVALID, "output arrays are NULL");
+    const int has_since = since_ms != LBH_SINCE_NONE;
+    if ((has_since && !created_ms_dev) || (tag_mask && !tagmask_dev)) return fail(LBH_E_INVALID, "a filter needs its column");
+    if (!(max_row_norm >= 0.0) || !(max_row_norm <= 1e15)) return fail(LBH_E_INVALID, "max_row_norm must be in [0, 1e15]");
+    const double qn = vec_norm(q_f64);
+    if (!(qn <= 1e15)) return fail(LBH_E_INVALID, "query vector is not finite (or its norm exceeds 1e15)");
+    std::lock_guard<std::mutex> lk(c->noalloc_mu);
+    HIP_TRY(hipSetDevice(c->device));
+    lbh_dev_index dv;
+    dv.emb32 = emb32_dev; dv.emb64 = emb64_dev; dv.created = created_ms_dev; dv.tags = tagmask_dev; dv.keys = keywords_dev; dv.n = n;
+    if (n == 0 || k == 0) {  // nothing to scan: only the count is written (stream-ordered, like everything else here)
+        HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return LBH_OK;
+    }
+    lbh_qarg qa;
+    memcpy(qa.q, q_f64, sizeof qa.q);  // travels inside the kernel-argument segment: no H2D copy
+    const double sc = std::min(std::max(max_row_norm * qn * (1.0 + 1e-6), 1e-30), 1e30);
+    HIP_TRY(lbh_launch_search_noalloc(c->noalloc_scratch, dv, qa, (int)std::min<int64_t>(k, n), has_since, since_ms, tag_mask, c->n_cu, c->scan_nt,
+                                      LBH_MARGIN * (float)sc, out_rows_dev, out_scores_dev, out_count_dev, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LBH_OK;
 }
 
 int lbh_index_search_shard(lbh_index* ix, const double* q_f64, int64_t k, int64_t since_ms, uint64_t tag_mask,

@@ -159,3 +159,8 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* em
                                      int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, float norm_scale, hipStream_t s,
                                      hipEvent_t ev0, hipEvent_t ev1);
 
+// allocation-free search: per-device address of the file-scope scratch array, and the launch sequence on it
+hipError_t lbh_noalloc_init(void** out_ptr);
+hipError_t lbh_launch_search_noalloc(void* scratch_ptr, const lbh_dev_index& ix, const lbh_qarg& qa, int k, int has_since,
+                                     int64_t since_ms, uint64_t tag_mask, int n_cu, int nt, float margin,
+                                     int64_t* out_rows_dev, double* out_scores_dev, int64_t* out_count_dev, hipStream_t s);

@@ -1835,6 +1835,89 @@ hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace&
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Allocation-free search (lbh_search_dev_noalloc): the same scan / select kernels, with every scratch
+// buffer they need -- the flat candidate list, the exact path's candidate arrays, the counters and the
+// result block -- carved out of ONE file-scope device array instead of the index's hipMalloc'd workspace.
+// Each GPU the library runs on holds its own copy of the array until the process ends; the host only ever
+// uses the per-device address that hipGetSymbolAddress returned (lbh_noalloc_init), never the symbol's name.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int NA_FAST_BLOCKS = 512;    // scan grid cap of the allocation-free path
+constexpr int NA_EXACT_BLOCKS = 128;
+constexpr size_t NA_OFF_CAND = 0;
+constexpr size_t NA_OFF_XORD = NA_OFF_CAND + (size_t)NA_FAST_BLOCKS * LBH_LIST_CAP * 8;                        // 1 MiB
+constexpr size_t NA_OFF_XROW = NA_OFF_XORD + (size_t)NA_EXACT_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 8;      // + 256 KiB
+constexpr size_t NA_OFF_FLAGS = NA_OFF_XROW + (size_t)NA_EXACT_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 4;     // + 128 KiB
+constexpr size_t NA_OFF_RESULT = NA_OFF_FLAGS + 256;
+constexpr size_t NA_BYTES = NA_OFF_RESULT + ((sizeof(lbh_result) + 255) / 256) * 256;
+static_assert(NA_BYTES == LBH_NOALLOC_SCRATCH_BYTES, "include/lbhip.h states the size of the scratch array");
+
+static __device__ __align__(256) unsigned char scratch[NA_BYTES];
+
+// device result block -> the caller's device buffers (rows as int64, fp64 scores, count; -1 = duplicate keys)
+__global__ void export_result_kernel(const lbh_result* __restrict__ res, int64_t* __restrict__ out_rows,
+                                     double* __restrict__ out_scores, int64_t* __restrict__ out_count) {
+    const int t = threadIdx.x;
+    const int cnt = res->overflow ? 0 : res->count;
+    if (t < cnt) {
+        out_rows[t] = (int64_t)res->rows[t];
+        out_scores[t] = res->scores[t];
+    }
+    if (t == 0) *out_count = res->overflow ? -1 : cnt;
+}
+}  // namespace
+
+hipError_t lbh_noalloc_init(void** out_ptr) {
+    // the symbol's name is a host-side stand-in; the array's address on the CURRENT device comes from the runtime
+    return hipGetSymbolAddress(out_ptr, HIP_SYMBOL(scratch));
+}
+
+hipError_t lbh_launch_search_noalloc(void* scratch_ptr, const lbh_dev_index& ix, const lbh_qarg& qa, int k, int has_since,
+                                     int64_t since_ms, uint64_t tag_mask, int n_cu, int nt, float margin,
+                                     int64_t* out_rows_dev, double* out_scores_dev, int64_t* out_count_dev, hipStream_t s) {
+    unsigned char* base = static_cast<unsigned char*>(scratch_ptr);
+    uint64_t* cand = reinterpret_cast<uint64_t*>(base + NA_OFF_CAND);
+    uint64_t* xord = reinterpret_cast<uint64_t*>(base + NA_OFF_XORD);
+    uint32_t* xrow = reinterpret_cast<uint32_t*>(base + NA_OFF_XROW);
+    int32_t* flags = reinterpret_cast<int32_t*>(base + NA_OFF_FLAGS);
+    lbh_result* res = reinterpret_cast<lbh_result*>(base + NA_OFF_RESULT);
+    // the array keeps the last call's contents: counters and the result header must start at zero
+    hipError_t e = hipMemsetAsync(flags, 0, 256 + 64, s);
+    if (e != hipSuccess) return e;
+    int grid = lbh_scan_grid(ix.n, n_cu, 2);
+    if (grid > NA_FAST_BLOCKS) grid = NA_FAST_BLOCKS;
+    const dim3 g(grid), b(LBH_SCAN_THREADS);
+#define LBH_NA_ARGS ix, nullptr, nullptr, qa, k, margin, since_ms, tag_mask, cand, flags
+    if (nt) {
+        if (has_since && tag_mask) scan_f32_kernel<true, true, true, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
+        else if (has_since) scan_f32_kernel<true, false, true, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
+        else if (tag_mask) scan_f32_kernel<false, true, true, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
+        else scan_f32_kernel<false, false, true, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
+    } else {
+        if (has_since && tag_mask) scan_f32_kernel<true, true, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
+        else if (has_since) scan_f32_kernel<true, false, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
+        else if (tag_mask) scan_f32_kernel<false, true, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
+        else scan_f32_kernel<false, false, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
+    }
+#undef LBH_NA_ARGS
+    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, nullptr, qa, k, cand, flags, res, 1, margin);
+    // mass near-ties (res->overflow == 1): the exact fp64 path decides; both kernels return at once otherwise.  No host
+    // round trip in between, so the whole sequence is stream-ordered.
+    lbh_cursor cur;
+    cur.active = 0; cur.ord = 0; cur.key[0] = cur.key[1] = cur.key[2] = cur.key[3] = 0;
+    const dim3 gx(grid < NA_EXACT_BLOCKS ? grid : NA_EXACT_BLOCKS);
+#define LBH_NAX_ARGS ix, nullptr, qa, k, since_ms, tag_mask, cur, xord, xrow, flags, &res->overflow
+    if (has_since && tag_mask) scan_exact_kernel<true, true><<<gx, b, 0, s>>>(LBH_NAX_ARGS);
+    else if (has_since) scan_exact_kernel<true, false><<<gx, b, 0, s>>>(LBH_NAX_ARGS);
+    else if (tag_mask) scan_exact_kernel<false, true><<<gx, b, 0, s>>>(LBH_NAX_ARGS);
+    else scan_exact_kernel<false, false><<<gx, b, 0, s>>>(LBH_NAX_ARGS);
+#undef LBH_NAX_ARGS
+    select_exact_kernel<<<1, SEL_THREADS, 0, s>>>(ix, k, xord, xrow, flags, res, 2, &res->overflow);
+    export_result_kernel<<<1, LBH_MAX_PAGE, 0, s>>>(res, out_rows_dev, out_scores_dev, out_count_dev);
+    return hipGetLastError();
+}
+
 hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, int nq, int k, int has_since,
                                      int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, float norm_scale, hipStream_t s,
                                      hipEvent_t ev0, hipEvent_t ev1) {
