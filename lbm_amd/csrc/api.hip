@@ -222,19 +222,22 @@ hipError_t wait_ticket(lbh_ctx* c, const int32_t* ticket, int32_t seq) {
     return hipStreamSynchronize(c->stream);
 }
 
-// fp16 copy for scan_mode 1: allocate with the index capacity, convert the rows that are not in it yet
+// fp16 copy (tiled, lbh_emb16_off) for the fp16 scans: allocate with the index capacity rounded up to whole 32-row
+// tiles, zero-filled (the pad rows of the last tile are read and masked, never trusted), convert the rows that are
+// not in it yet
 int ensure_emb16(lbh_index* ix) {
     hipStream_t s = ix->ctx->stream;
     if (!ix->emb16 || ix->emb16_cap < ix->cap) {
         if (ix->emb16) (void)hipFree(ix->emb16);
         ix->emb16 = nullptr;
         ix->emb16_rows = ix->emb16_cap = 0;
-        HIP_TRY(hipMalloc((void**)&ix->emb16, (size_t)ix->cap * 128));
+        const size_t bytes = (size_t)((ix->cap + 63) / 64) * 64 * 128;
+        HIP_TRY(hipMalloc((void**)&ix->emb16, bytes));
+        HIP_TRY(hipMemsetAsync(ix->emb16, 0, bytes, s));
         ix->emb16_cap = ix->cap;
     }
     if (ix->emb16_rows < ix->n) {
-        HIP_TRY(lbh_launch_f64_to_f16(ix->emb64 + ix->emb16_rows * 64, ix->emb16 + ix->emb16_rows * 64,
-                                      (ix->n - ix->emb16_rows) * 64, s));
+        HIP_TRY(lbh_launch_f64_to_f16_tiled(ix->emb64, ix->emb16, ix->emb16_rows, ix->n, s));
         ix->emb16_rows = ix->n;
     }
     return LBH_OK;
@@ -374,6 +377,7 @@ int ensure_batched_ws(lbh_index* ix) {
     HIP_TRY(hipMalloc((void**)&w.bq_cand, (size_t)LBH_BQ_MAXQ * LBH_BQ_PERQ * 8));
     HIP_TRY(hipMalloc((void**)&w.bq_total, (size_t)LBH_BQ_MAXQ * 4));
     HIP_TRY(hipMalloc((void**)&w.bq_seed, (size_t)LBH_BQ_MAXQ * 4));
+    HIP_TRY(hipMalloc((void**)&w.bq_bfrag, (size_t)LBH_BQ_MAXQ * 128));
     HIP_TRY(hipHostMalloc((void**)&w.bq_result_host, sizeof(lbh_result) * LBH_BQ_MAXQ, hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer((void**)&w.bq_result_dev, w.bq_result_host, 0));
     return LBH_OK;
@@ -581,7 +585,7 @@ int lbh_index_destroy(lbh_index* ix) {
     (void)hipStreamSynchronize(ix->ctx->stream);
     lbh_workspace& w = ix->ws;
     void* dev[] = {ix->emb16, ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, ix->order, w.rc_a, w.rc_b, w.rc_row, w.rc_cnt, w.q64, w.cand, w.xcand_ord, w.xcand_row,
-                   w.flags, w.bq_qmat, w.bq_cand, w.bq_total, w.bq_seed};
+                   w.flags, w.bq_qmat, w.bq_cand, w.bq_total, w.bq_seed, w.bq_bfrag};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     for (auto& ev : ix->ev)
@@ -984,8 +988,8 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
             if (!(qn <= 1e15)) return fail(LBH_E_INVALID, "a query vector is not finite (or its norm exceeds 1e15)");
             HIP_TRY(hipMemcpyAsync(ix->ws.bq_qmat, q_f64 + q0 * 64, (size_t)nb * 512, hipMemcpyHostToDevice, s));
             const float nscale = norm_scale(ix, qn);
-            // scan_mode 1 keeps an fp16 copy of the matrix: the fp16 kernel then streams 128 B/claim and skips the conversion
-            const bool src16 = c->scan_mode == 1 && c->bq_mode == 2 && nscale >= 0.25f && nscale <= 1.001f;
+            // the fp16 kernel streams the fp16 copy of the matrix (128 B/claim, MFMA-fragment order; built on first use)
+            const bool src16 = c->bq_mode == 2 && nscale >= 0.25f && nscale <= 1.001f;
             if (src16) {
                 const int rc16 = ensure_emb16(ix);
                 if (rc16) return rc16;

@@ -328,10 +328,21 @@ __global__ void f64_to_f32_kernel(const double* __restrict__ in, float* __restri
         out[i] = (float)in[i];
 }
 
-// fp16 copy of the matrix for the opt-in fp16 scan: round to nearest even (the scan's error bound assumes it)
-__global__ void f64_to_f16_kernel(const double* __restrict__ in, _Float16* __restrict__ out, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = (_Float16)(float)in[i];
+// fp16 copy of the matrix (fp16 scans): rows [row0, row1) of emb64 -> tiled emb16 (layout: lbh_emb16_off).  One
+// rounding to nearest even straight from the stored fp64 value (the scans' error bound assumes it; a detour through
+// fp32 would round twice).  One thread per (row, group of 8 dims): 64 B in, one 16-byte store out.
+typedef _Float16 e_f16x8 __attribute__((ext_vector_type(8)));
+__global__ void f64_to_f16_tiled_kernel(const double* __restrict__ emb64, _Float16* __restrict__ emb16, int64_t row0, int64_t row1) {
+    const int64_t total = (row1 - row0) * 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = row0 + (i >> 3);
+        const int g = (int)(i & 7);
+        const double* src = emb64 + row * 64 + g * 8;
+        e_f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (_Float16)src[e];
+        *reinterpret_cast<e_f16x8*>(emb16 + lbh_emb16_off(row, g * 8)) = v;
+    }
 }
 
 // swap-delete support: copy row `src` over row `dst` in every per-claim array
@@ -339,7 +350,7 @@ __global__ void move_row_kernel(float* emb32, double* emb64, uint16_t* emb16, in
                                 uint64_t* order, int64_t dst, int64_t src) {
     const int l = threadIdx.x;
     emb32[dst * 64 + l] = emb32[src * 64 + l];
-    if (emb16) emb16[dst * 64 + l] = emb16[src * 64 + l];
+    if (emb16) emb16[lbh_emb16_off(dst, l)] = emb16[lbh_emb16_off(src, l)];
     emb64[dst * 64 + l] = emb64[src * 64 + l];
     if (l < 4) keys[dst * 4 + l] = keys[src * 4 + l];
     if (l == 4) created[dst] = created[src];
@@ -356,7 +367,7 @@ __global__ void move_rows_kernel(float* emb32, double* emb64, uint16_t* emb16, i
     if (p >= n_pairs) return;
     const int64_t dst = pairs[2 * p], src = pairs[2 * p + 1];
     emb32[dst * 64 + l] = emb32[src * 64 + l];
-    if (emb16) emb16[dst * 64 + l] = emb16[src * 64 + l];
+    if (emb16) emb16[lbh_emb16_off(dst, l)] = emb16[lbh_emb16_off(src, l)];
     emb64[dst * 64 + l] = emb64[src * 64 + l];
     if (l < 4) keys[dst * 4 + l] = keys[src * 4 + l];
     if (l == 4) created[dst] = created[src];
@@ -427,11 +438,11 @@ hipError_t lbh_launch_gather_rows_f64(const double* emb64, const int64_t* rows_d
     return hipGetLastError();
 }
 
-hipError_t lbh_launch_f64_to_f16(const double* in_dev, uint16_t* out_dev, int64_t n_elems, hipStream_t s) {
-    if (n_elems <= 0) return hipSuccess;
-    int64_t blocks = (n_elems + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    f64_to_f16_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(in_dev, reinterpret_cast<_Float16*>(out_dev), n_elems);
+hipError_t lbh_launch_f64_to_f16_tiled(const double* emb64_dev, uint16_t* emb16_dev, int64_t row0, int64_t row1, hipStream_t s) {
+    if (row1 <= row0) return hipSuccess;
+    int64_t blocks = ((row1 - row0) * 8 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    f64_to_f16_tiled_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(emb64_dev, reinterpret_cast<_Float16*>(emb16_dev), row0, row1);
     return hipGetLastError();
 }
 

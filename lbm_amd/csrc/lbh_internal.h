@@ -47,6 +47,15 @@ __host__ __device__ inline double lbh_unord64(uint64_t o) {
     return __builtin_bit_cast(double, b);
 }
 
+// ---- fp16 copy of the claim matrix (emb16): stored in MFMA-fragment order -------------------------------------
+// A tile = 32 consecutive rows = 4 KiB = four 1-KiB chunks, one per k-step s of v_mfma_f32_32x32x16_f16.  Chunk s holds,
+// for lane L = 32 h + j, the 8 halves dims 16 s + 8 h .. + 7 of row 32 t + j at byte 16 L: a wave reads a whole A
+// fragment with ONE fully coalesced global_load_dwordx4, no LDS staging and no conversion, and the single-query fp16
+// scan streams the same chunks (a lane then holds 8 dims of one row per load).  Capacity is padded to whole tiles.
+__host__ __device__ inline int64_t lbh_emb16_off(int64_t row, int d) {  // offset in halves of element (row, d)
+    return (row >> 5) * 2048 + (int64_t)(d >> 4) * 512 + (int64_t)((((d >> 3) & 1) << 5) + (row & 31)) * 8 + (d & 7);
+}
+
 // ---- device arrays of one index (all row-major, row r at the natural offset) ------------------
 struct lbh_dev_index {
     const float* emb32;       // n x 64 fp32   (256 B rows)  -- the scan copy
@@ -112,6 +121,7 @@ struct lbh_workspace {
     uint64_t* bq_cand;        // 256 x LBH_BQ_PERQ flat candidate lists, one per query
     int32_t* bq_total;        // 256 counters
     uint32_t* bq_seed;        // 256 per-query seed thresholds (ord32) from the sample pass
+    void* bq_bfrag;           // 32 KiB: the queries as fp16 MFMA B fragments (scan_batched_tiled_kernel)
     lbh_result* bq_result_host;  // 256 results, pinned + device-mapped
     lbh_result* bq_result_dev;
     // recency query (get_recent_claims) workspace, allocated on first use
@@ -137,7 +147,7 @@ hipError_t lbh_launch_move_row(float* emb32, double* emb64, uint16_t* emb16, int
 hipError_t lbh_launch_move_rows(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
                                 uint64_t* order, const int64_t* pairs_dev, int64_t n_pairs, hipStream_t s);
 hipError_t lbh_launch_gather_rows_f64(const double* emb64, const int64_t* rows_dev, int64_t n, double* out_dev, hipStream_t s);
-hipError_t lbh_launch_f64_to_f16(const double* in_dev, uint16_t* out_dev, int64_t n_elems, hipStream_t s);
+hipError_t lbh_launch_f64_to_f16_tiled(const double* emb64_dev, uint16_t* emb16_dev, int64_t row0, int64_t row1, hipStream_t s);
 hipError_t lbh_launch_iota_u64(uint64_t* dst, uint64_t first, int64_t n, hipStream_t s);
 hipError_t lbh_launch_scatter_u64(uint64_t* dst, const int64_t* rows_dev, const uint64_t* vals_dev, int64_t n, hipStream_t s);
 // search.hip

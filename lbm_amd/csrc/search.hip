@@ -17,6 +17,7 @@
 //
 // This file is compiled with -ffp-contract=off: fp64 arithmetic must round like CPython floats.
 // FMAs in the fp32 scan are written explicitly (fmaf).
+#include <cmath>
 #include <cstdlib>
 #include <mutex>
 
@@ -128,11 +129,15 @@ __device__ __forceinline__ double exact_dot_latency(const double* __restrict__ q
 // reduction tree, so bit-identical rows get bit-identical scores wherever they sit.
 // ------------------------------------------------------------------------------------------------
 //
-// HALF = true is the opt-in fp16 flavour (`scan_mode` 1): it streams a 128 B/claim fp16 copy of the matrix instead
-// (lane l, load j: halves [8c, 8c+8) of tile row 8j + g, c = l & 7, g = l >> 3; three butterfly steps), scores with
-// fp32 FMAs of the (exact) fp16 products and cuts with the fp16 margin (LBH_MARGIN_F16, see scan_batched_f16_kernel for the bound).  The
-// exact re-rank makes the result identical; only the bytes per claim change.
+// HALF = true is the opt-in fp16 flavour (`scan_mode` 1): it streams the 128 B/claim fp16 copy of the matrix instead.
+// The copy is stored in MFMA-fragment order (lbh_emb16_off): a 64-row step is 8 KiB = two 32-row tiles x four 1-KiB
+// chunks; lane (j = l & 31, h = l >> 5) gets, from chunk s of tile u, the 8 halves dims 16 s + 8 h .. + 7 of row
+// 32 u + j.  Each lane sums its 32 products per tile in fp32 (v_dot2_f32_f16), ONE cross-half exchange completes the
+// two tiles' scores at once (lane (j, h) ends up with row 32 h + j), and the candidate cut uses the fp16 margin
+// (LBH_MARGIN_F16, see scan_batched_tiled_kernel for the bound).  The exact re-rank makes the result identical; only
+// the bytes per claim change.
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 
 template <bool SINCE, bool TAGS, bool NT, bool HALF>
 __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_index ix, const uint16_t* __restrict__ emb16,
@@ -146,22 +151,26 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int c = HALF ? (lane & 7) : (lane & 15), g = HALF ? (lane >> 3) : (lane >> 4);
+    const int c = lane & 15, g = lane >> 4;     // fp32 matrix: 16-byte chunk of a row / row within a 4-row load
+    const int hj = lane & 31, hh = lane >> 5;   // fp16 copy: row within a 32-row tile / which 8 dims of every k-step
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     // query: device pointer (search_text: embedded on the GPU) or the kernel-argument copy (no H2D copy)
     const double* __restrict__ qd = qptr ? qptr : qa.q;
     const f32x4 qf = {(float)qd[4 * (c & 15)], (float)qd[4 * (c & 15) + 1], (float)qd[4 * (c & 15) + 2], (float)qd[4 * (c & 15) + 3]};
-    h2_t qh[4];  // HALF: this lane's 8 query dims as packed fp16 (round to nearest even)
+    h2_t qh[4][4];  // HALF: this lane's 32 query dims (16 s + 8 hh + 2 e, + 1) as packed fp16, one rounding to nearest even
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        qh[e].x = (_Float16)(float)qd[8 * (c & 7) + 2 * e];
-        qh[e].y = (_Float16)(float)qd[8 * (c & 7) + 2 * e + 1];
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            qh[ks][e].x = (_Float16)qd[16 * ks + 8 * hh + 2 * e];
+            qh[ks][e].y = (_Float16)qd[16 * ks + 8 * hh + 2 * e + 1];
+        }
     }
     const f32x4* __restrict__ E = reinterpret_cast<const f32x4*>(ix.emb32);
     const f32x4* __restrict__ E16 = reinterpret_cast<const f32x4*>(emb16);
     const int64_t n = ix.n;
     const int64_t n_tiles = (n + 63) >> 6;
-    const int64_t n_vec = n * (HALF ? 8 : 16);  // 16-byte chunks in the scanned matrix
+    const int64_t n_vec = n * 16;  // 16-byte chunks in the fp32 matrix (the fp16 copy is padded to whole 64-row steps)
     uint64_t* buf = wbuf[wave];
 
     uint32_t thr = 0;  // ordered image of (k-th best so far - margin); 0 admits everything
@@ -234,41 +243,31 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
         } else {
             const int64_t v0 = tile * 512 + lane;
             f32x4 x[8];  // 16 raw bytes = 8 halves per load (typed as floats only to reuse the 128-bit load path)
-            if (v0 + 512 - lane <= n_vec) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = NT ? __builtin_nontemporal_load(&E16[v0 + j * 64]) : E16[v0 + j * 64];
-            } else {
+            for (int j = 0; j < 8; ++j) x[j] = NT ? __builtin_nontemporal_load(&E16[v0 + j * 64]) : E16[v0 + j * 64];
+            myrow = tile * 64 + 32 * hh + hj;
+            float p[2];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = (v0 + j * 64 < n_vec) ? E16[v0 + j * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            myrow = tile * 64 + 8 * c + g;
-            float p[8];
+            for (int u = 0; u < 2; ++u) {
+                float a = 0.f;  // fp16 x fp16 products are exact in fp32; fp32 accumulation
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float a = 0.f;  // fp16 x fp16 products are exact in fp32; eight fp32 accumulations per chunk
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float xw = e == 0 ? x[j].x : e == 1 ? x[j].y : e == 2 ? x[j].z : x[j].w;
-                    const h2_t xe = __builtin_bit_cast(h2_t, xw);
-                    a = fmaf((float)xe.x, (float)qh[e].x, a);
-                    a = fmaf((float)xe.y, (float)qh[e].y, a);
+                for (int ks = 0; ks < 4; ++ks) {
+                    // whole-vector bit cast, then element pairs: a bit cast of the single floats .x/.y/.z/.w to half pairs
+                    // made hipcc 7.2 use word 0 of the chunk four times (seen in the ISA; same family of bug as the
+                    // loop-indexed integer vector noted in DESIGN.md)
+                    const h8_t xv = __builtin_bit_cast(h8_t, x[u * 4 + ks]);
+                    a = __builtin_amdgcn_fdot2(h2_t{xv[0], xv[1]}, qh[ks][0], a, false);
+                    a = __builtin_amdgcn_fdot2(h2_t{xv[2], xv[3]}, qh[ks][1], a, false);
+                    a = __builtin_amdgcn_fdot2(h2_t{xv[4], xv[5]}, qh[ks][2], a, false);
+                    a = __builtin_amdgcn_fdot2(h2_t{xv[6], xv[7]}, qh[ks][3], a, false);
                 }
-                p[j] = a;
+                p[u] = a;
             }
-            float r4[4], r2[2];
-            const bool b4 = c & 4, b2 = c & 2, b1 = c & 1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float keep = b4 ? p[j + 4] : p[j], send = b4 ? p[j] : p[j + 4];
-                r4[j] = keep + __shfl_xor(send, 4);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float keep = b2 ? r4[j + 2] : r4[j], send = b2 ? r4[j] : r4[j + 2];
-                r2[j] = keep + __shfl_xor(send, 2);
-            }
-            const float keep1 = b1 ? r2[1] : r2[0], send1 = b1 ? r2[0] : r2[1];
-            s = keep1 + __shfl_xor(send1, 1);
+            // lane (j, 0) holds the hh = 0 half of both tiles' row j, lane (j, 1) the other half: each keeps the tile it
+            // will report (u = hh) and sends the other one across; the sum is commutative, so a row gets the same score
+            // in either half of the wave
+            const float keep = hh ? p[1] : p[0], send = hh ? p[0] : p[1];
+            s = keep + __shfl_xor(send, 32);
         }
         bool valid = myrow < n;
         if (SINCE) valid = valid && (ix.created[valid ? myrow : 0] >= since_ms);
@@ -566,9 +565,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index 
 // its registers, so the running threshold of a query is a per-lane register and the since/tag mask is
 // one 32-bit word per tile.  Candidates go to per-query LDS buffers (BQ_CAP entries); a buffer above
 // BQ_TRIG entries is cut at (k-th best - margin) by rank counting (one query) or by per-lane top-k lists
-// (all queries of the wave at once).  Three scan precisions share this machinery: scan_batched_kernel
-// <.., BF16 = false> (exact fp32 products), <.., BF16 = true> (split bf16, three products) and
-// scan_batched_f16_kernel (one fp16 product, the default); the margin is twice the error bound of each.
+// (all queries of the wave at once).  Two scan precisions share this machinery: scan_batched_kernel
+// <.., BF16 = false> (exact fp32 products) and <.., BF16 = true> (split bf16, three products); the default
+// precision (one fp16 product) has its own, barrier-free kernel further down (scan_batched_tiled_kernel).  The
+// margin is twice the error bound of each.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef LBH_BQ_ABLATE
@@ -1012,99 +1012,160 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3, fp16 flavour: ONE v_mfma_f32_32x32x16_f16 product per k-step (4 MFMAs per 32x32 tile instead of 12).
-// Why: the split-bf16 kernel above is power-bound, not issue-bound.  tools/mfma_rate.hip measures 13.4 ns
-// per 32x32x16 MFMA on an idle chip, 16.7 ns with every CU issuing and 20 ns with random operand bits
-// (the clock drops under matrix load); three re-orderings of that kernel (phase-staggered waves, staging
-// slices between the MFMAs, alternating chains) all ran in 1.13-1.18 ms, and a timing-only build with a
-// third of the MFMAs took 0.52 ms.  Less matrix work is the only lever, and the exact re-rank makes it safe:
-// the scan only has to bound its error.  fp16 keeps 11 significant bits, so |fp16(x) fp16(q) - x q| <=
-// (2^-11 + 2^-11 + 2^-22) |x q|; summed over a pair of unit vectors (sum |x_i q_i| <= 1) that is < 9.8e-4,
-// plus 64 fp32 accumulations (< 1e-5) and fp16 denormal flushes of components below 6e-5 (< 64 * 6e-5 * 6e-5).
-// eps < 1e-3, margin LBH_MARGIN_F16 = 2.2e-3 > 2 eps.  On the bench corpus that admits < 1 extra candidate per
-// query and million claims.  Same LDS rows (272 B; the fp16 image uses the first 128), same candidate code.
+// K3, fp16 flavour (the default): ONE v_mfma_f32_32x32x16_f16 product per k-step (4 MFMAs per 32 x 32 tile), claim
+// tiles PRIVATE to a wave.
+//
+// Why fp16: the split-bf16 kernel above is power-bound, not issue-bound (tools/mfma_rate.hip: 13.4 ns per 32x32x16 MFMA
+// on an idle chip, 16.7 ns with every CU issuing, 20 ns with random operand bits); less matrix work is the only lever
+// and the exact re-rank makes it safe: the scan only has to bound its error.  fp16 keeps 11 significant bits, so
+// |fp16(x) fp16(q) - x q| <= (2^-11 + 2^-11 + 2^-22) |x q|; summed over a pair of unit vectors (sum |x_i q_i| <= 1)
+// that is < 9.8e-4, plus 64 fp32 accumulations (< 1e-5) and fp16 denormal flushes of components below 6e-5
+// (< 64 * 6e-5 * 6e-5).  eps < 1e-3, margin LBH_MARGIN_F16 = 2.2e-3 > 2 eps.
+//
+// Why wave-private tiles (round 2): the round-1 kernel staged every 64-claim super-tile through LDS for eight waves
+// that each owned 32 queries, with one workgroup barrier per super-tile; a candidate in any of the 256 queries held up
+// all eight waves at the next barrier, the 256 per-query LDS candidate buffers left room for one workgroup per CU, and
+// the kernel ran at 0.74 us per super-tile against 0.21 us of matrix time (profiles/r01_k3_wave_timeline.txt).  Here
+//   * the fp16 copy of the matrix is stored in MFMA-fragment order (lbh_emb16_off): a wave fetches the A fragments of a
+//     32-claim tile with four coalesced 1-KiB global_load_dwordx4 straight into registers -- no LDS image, no
+//     conversion, no barrier anywhere in the kernel; three tiles are in flight per wave;
+//   * the wave multiplies its tile by ALL query groups: the B fragments of up to 256 queries (8 groups x 4 k-steps x
+//     16 B per lane = 128 VGPRs) stay in registers for the whole launch, loaded once from a pre-converted image;
+//   * a lane's threshold for each of its 8 queries is a register; the common-case epilogue of a 32 x 32 block is the
+//     lane maximum (8 v_max3_f32), one compare, one wave vote.  Thresholds are FIXED for a launch (see the passes
+//     below), so there is no candidate buffer to compact: the rare hits go to a 256-entry per-wave staging list in LDS
+//     (ballot-prefix append) that is flushed to the queries' flat lists in HBM with one atomic per entry -- in the
+//     steady state once, at the end of the kernel.  A hit stalls only the wave that found it.
+// Passes (lbh_launch_search_batched_tiled): (1) DENSE: every score of <= 8192 rows, taken as 256 tiles spread evenly
+// over the index, is written to the lists; seed_batched_kernel turns each query's k-th best into a threshold (a
+// subset's k-th best, minus the margin, never exceeds the final cut).  (2) zero or more intermediate passes over
+// evenly spread subsets, each R times larger than the last, each starting from the previous pass's thresholds: the
+// number of rows above the k-th best of a 1/R subset is about k R whatever the score distribution (order statistics
+// of an evenly spread subset), so R is chosen to keep that near 2048 / a list of 8192.  (3) the full pass.  At 10 M
+// claims, top-8: 8192 rows -> 286 k rows -> 10 M rows, ~280 list entries per query and pass.
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-#if LBH_BQ_ABLATE == 10
-__device__ long long lbh_k3_dbg[3][256][5];  // start, end, after prologue, (same), after loop: 100 MHz wall-clock ticks
+constexpr int K3T_THREADS = 256;    // 4 waves; two workgroups per CU = two waves per SIMD, 256 VGPRs each
+constexpr int K3T_WAVES = K3T_THREADS / 64;
+constexpr int K3T_STAGE = 256;      // per-wave staging list (entries)
+#ifndef K3T_RING
+#define K3T_RING 3                  // claim tiles in flight per wave (register sets)
 #endif
-template <bool SINCE, bool TAGS, bool SRC16>
-__global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_index ix, const uint16_t* __restrict__ emb16,
-                                                                       const double* __restrict__ qmat,
-                                                                       int nq, int k, float margin, int64_t since_ms, uint64_t tag_mask,
-                                                                       int64_t row_begin, int64_t row_end,
-                                                                       const uint32_t* __restrict__ seed,
-                                                                       uint64_t* __restrict__ cand3,
-                                                                       int32_t* __restrict__ qtotal,
-                                                                       int32_t* __restrict__ flags) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* qbuf = reinterpret_cast<uint64_t*>(smem);
-    float* tile = reinterpret_cast<float*>(smem + (size_t)BQ_MAXQ * BQ_CAP * 8);
-    int* qcnt = reinterpret_cast<int*>(smem + (size_t)BQ_MAXQ * BQ_CAP * 8 + BQ_NBUF * BQ_TILE_F * 4);
-    uint32_t* qthr = reinterpret_cast<uint32_t*>(qcnt + BQ_MAXQ);
+constexpr int K3T_DENSE_TILES = BQ_PERQ / 32;  // tiles whose every score fits a query's list
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const int myq = wave * 32 + j;
-    const bool qactive = myq < nq;
-    const bool wave_active = wave * 32 < nq;
-    const int64_t n = row_end < ix.n ? row_end : ix.n;
-    const f32x4* __restrict__ E = reinterpret_cast<const f32x4*>(ix.emb32);
+// B operand image: [group g][k-step s][lane] x 16 B = dims 16 s + 8 h .. + 7 of query 32 g + j as fp16 (one rounding
+// from the fp64 query); queries >= nq are zero
+__global__ void prep_bfrag_kernel(const double* __restrict__ qmat, int nq, f16x8* __restrict__ bfrag) {
+    const int lane = threadIdx.x & 63, s = (threadIdx.x >> 6) & 3, g = blockIdx.x;
+    const int j = lane & 31, h = lane >> 5, q = 32 * g + j;
+    f16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = q < nq ? (_Float16)qmat[(size_t)q * 64 + 16 * s + 8 * h + e] : (_Float16)0.f;
+    bfrag[(g * 4 + s) * 64 + lane] = v;
+}
 
-#if LBH_BQ_ABLATE == 10  // instrumented build (tools/scripts/k3_phases.py): phase times of every workgroup's first wave
-    const long long t_start = wall_clock64();
-    long long t_pro = 0, t_loop = 0;
-#endif
-    if (tid < BQ_MAXQ) { qcnt[tid] = 0; qthr[tid] = (seed && tid < nq) ? seed[tid] : 0u; }
-    f16x8 bq[4];  // B operand: k-step s holds dims 16s + 8h .. +7 of this lane's query
+// staging list -> the queries' flat lists in HBM: one atomic per entry (a handful per wave and launch in the steady state)
+__device__ __forceinline__ void k3t_flush(const uint64_t* se, const uint16_t* sq, int cnt, int lane, uint64_t* __restrict__ cand3,
+                                          int32_t* __restrict__ qtotal) {
+    for (int i = lane; i < cnt; i += 64) {
+        const uint64_t e = se[i];
+        const int q = sq[i];
+        const int pos = atomicAdd(&qtotal[q], 1) & (BQ_OVER - 1);
+        if (pos < BQ_PERQ) cand3[(size_t)q * BQ_PERQ + pos] = e;
+        else atomicOr(&qtotal[q], BQ_OVER);  // more near-candidates than the list holds: that query is re-run alone
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Slow path of the tiled kernel, deliberately OUT OF LINE: the scan loop holds 24 copies of the 32 x 32 epilogue (3 ring
+// slots x 8 query groups); with this code inlined into each of them the loop body was 290 KB of instructions, the fast
+// path hopped from one instruction-cache miss to the next and the full pass ran 3x slower than the round-1 kernel.  One
+// shared copy stays resident.  Returns the new fill of the wave's staging list.
+template <bool SINCE, bool TAGS>
+__device__ __noinline__ int k3t_harvest(f32x16 acc, float thr, bool lanehit, int q, int64_t row0, int64_t n,
+                                        const int64_t* __restrict__ created, const uint64_t* __restrict__ tags,
+                                        int64_t since_ms, uint64_t tag_mask, uint64_t* se, uint16_t* sq, int cnt,
+                                        uint64_t* __restrict__ cand3, int32_t* __restrict__ qtotal) {
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    uint32_t rmask = 0xFFFFFFFFu;  // rows of the tile that exist and pass the since / tag filters
+    if (SINCE || TAGS || row0 + 32 > n) {
+        bool rv = false;
+        if (lane < 32) {
+            const int64_t r = row0 + lane;
+            rv = r < n;
+            if (SINCE) rv = rv && created[rv ? r : 0] >= since_ms;
+            if (TAGS) rv = rv && (tags[r < n ? r : 0] & tag_mask) != 0;
+        }
+        rmask = (uint32_t)__ballot(rv);
+    }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float v0 = (float)qmat[(size_t)(qactive ? myq : 0) * 64 + 16 * s + 8 * h + e];
-            bq[s][e] = (_Float16)(qactive ? v0 : 0.f);
+    for (int r = 0; r < 16; ++r) {
+        const int rowbit = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool pass = lanehit && acc[r] >= thr && ((rmask >> rowbit) & 1u);
+        const uint64_t pm = __ballot(pass);
+        if (pm) {
+            if (cnt + 64 > K3T_STAGE) {
+                k3t_flush(se, sq, cnt, lane, cand3, qtotal);
+                cnt = 0;
+            }
+            if (pass) {
+                const int pos = cnt + __popcll(pm & lt_mask);
+                se[pos] = ((uint64_t)lbh_ord32(acc[r]) << 32) | (uint32_t)(row0 + rowbit);
+                sq[pos] = (uint16_t)q;
+            }
+            cnt += __popcll(pm);
         }
     }
-    uint32_t thr = (seed && qactive) ? seed[myq] : 0u;
-    float thr_f = qactive ? (thr ? lbh_unord32(thr) : -__builtin_inff()) : __builtin_inff();
+    __builtin_amdgcn_wave_barrier();
+    return cnt;
+}
 
-    const int64_t n_super = n > row_begin ? (n - row_begin + 63) >> 6 : 0;
-    const int64_t G = gridDim.x;
-    int64_t st = blockIdx.x;
-    const int srow = tid >> 4, sc4 = tid & 15;
-    auto load_half = [&](int64_t sti, int half) -> f32x4 {  // always issued, row clamped (see the first kernel)
-        int64_t r = row_begin + sti * 64 + half * 32 + srow;
-        r = r < n ? r : n - 1;
-        return __builtin_nontemporal_load(&E[r * 16 + sc4]);
+template <bool SINCE, bool TAGS, bool DENSE>
+__global__ __launch_bounds__(K3T_THREADS, 2) void scan_batched_tiled_kernel(
+    lbh_dev_index ix, const f32x4* __restrict__ emb16t, const f32x4* __restrict__ bfrag, int nq, int64_t since_ms,
+    uint64_t tag_mask, int64_t n_tiles, int64_t n_sel, uint64_t step_q32, const uint32_t* __restrict__ seed,
+    uint64_t* __restrict__ cand3, int32_t* __restrict__ qtotal) {
+    __shared__ uint64_t stage_e[K3T_WAVES][K3T_STAGE];
+    __shared__ uint16_t stage_q[K3T_WAVES][K3T_STAGE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int ngroups = (nq + 31) >> 5;
+    const int64_t n = ix.n;
+    uint64_t* se = stage_e[wave];
+    uint16_t* sq = stage_q[wave];
+    int cnt = 0;
+
+    // B fragments of every query group, resident for the whole launch
+    f16x8 bq[8][4];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bq[g][s] = __builtin_bit_cast(f16x8, bfrag[(g * 4 + s) * 64 + lane]);
+    }
+    // fixed thresholds of this lane's query in every group (+inf for a query slot that is not in use)
+    float thr[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int q = 32 * g + j;
+        const uint32_t o = (seed && q < nq) ? seed[q] : 0u;
+        thr[g] = q < nq ? (o ? lbh_unord32(o) : -__builtin_inff()) : __builtin_inff();
+    }
+
+    // the i-th selected tile: tiles spread evenly over the index ((i * n_tiles) / n_sel in 32.32 fixed point; distinct
+    // for distinct i because the step is >= 1)
+    auto tile_of = [&](int64_t i) -> int64_t {
+        const int64_t t = (int64_t)(((unsigned __int128)(uint64_t)i * step_q32) >> 32);
+        return t < n_tiles ? t : n_tiles - 1;
     };
-    // LDS image of a super-tile: 64 rows of 128 B + 16 B pad (conflict-free ds_read_b128), THREE buffers in the space
-    // the other kernels use for two 272-byte-row buffers
-    constexpr int TS16 = 36, TILE16 = 64 * TS16;
-    static_assert(3 * TILE16 <= BQ_NBUF * BQ_TILE_F, "three fp16 tile buffers must fit the tile area");
-    auto store_half = [&](int buf, int half, f32x4 v) {  // round-to-nearest-even conversion (the bound above needs it)
-        char* d = reinterpret_cast<char*>(tile + (size_t)buf * TILE16 + (half * 32 + srow) * TS16) + 8 * sc4;
-        *reinterpret_cast<f16x4*>(d) = __builtin_convertvector(v, f16x4);
+    auto load_tile = [&](f32x4 (&a)[4], int64_t i) {  // always issued (index clamped): no load under a lane-dependent guard
+        const int64_t t = tile_of(i < n_sel ? i : n_sel - 1);
+        const f32x4* p = emb16t + t * 256 + lane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[s] = __builtin_nontemporal_load(p + s * 64);
     };
-    // SRC16: the index keeps an fp16 copy of the matrix (scan_mode 1): a super-tile is 8 KiB, one 16-byte load and
-    // one ds_write_b128 per thread, no conversion
-    const f32x4* __restrict__ E16 = reinterpret_cast<const f32x4*>(emb16);
-    const int srow16 = tid >> 3, sc8 = tid & 7;
-    auto load16 = [&](int64_t sti) -> f32x4 {
-        int64_t r = row_begin + sti * 64 + srow16;
-        r = r < n ? r : n - 1;
-        return __builtin_nontemporal_load(&E16[r * 8 + sc8]);
-    };
-    auto store16 = [&](int buf, f32x4 v) {
-        char* d = reinterpret_cast<char*>(tile + (size_t)buf * TILE16 + srow16 * TS16) + 16 * sc8;
-        *reinterpret_cast<f32x4*>(d) = v;
-    };
-    bq_ctx bc;
-    bc.qbuf = qbuf; bc.qcnt = qcnt; bc.qthr = qthr; bc.qtotal = qtotal;
-    bc.k = k; bc.lane = lane; bc.wave = wave; bc.myq = myq; bc.h = h; bc.qactive = qactive;
-    bc.margin = margin;
-    auto row_mask = [&](int64_t row0) -> uint32_t {
+    auto row_mask = [&](int64_t row0) -> uint32_t {  // rows of the tile that exist and pass the since / tag filters
         bool rv = false;
         if (lane < 32) {
             const int64_t r = row0 + lane;
@@ -1114,150 +1175,94 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_f16_kernel(lbh_dev_in
         }
         return (uint32_t)__ballot(rv);
     };
-    auto lane_hit = [&](const f32x16& acc) -> bool {  // max of the 16 scores (8 v_max3_f32), one compare
-        float m = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
+
+    const int64_t W = (int64_t)gridDim.x * K3T_WAVES;
+    const int64_t i0 = (int64_t)blockIdx.x * K3T_WAVES + wave;
+
+    auto process = [&](const f32x4 (&araw)[4], int64_t i) {
+        const int64_t tile = tile_of(i);
+        const int64_t row0 = tile * 32;
+        f16x8 a[4];
 #pragma unroll
-        for (int r = 3; r < 15; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, acc[r]), acc[r + 1]);
-        m = __builtin_fmaxf(m, acc[15]);
-        return m >= thr_f;
-    };
-    auto harvest = [&](const f32x16& acc, int64_t row0, uint32_t rowmask, bool lanehit) {
-        thr = bq_harvest_lanes(bc, acc, row0, rowmask, thr, lanehit);
-        if (qactive) thr_f = thr ? lbh_unord32(thr) : -__builtin_inff();
+        for (int s = 0; s < 4; ++s) a[s] = __builtin_bit_cast(f16x8, araw[s]);
+        const bool plain = !SINCE && !TAGS && row0 + 32 <= n;
+        uint32_t rmask = 0xFFFFFFFFu;
+        if (DENSE && !plain) rmask = row_mask(row0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g < ngroups) {
+                f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[g][s], acc, 0, 0, 0);
+                const int q = 32 * g + j;
+                if (DENSE) {  // every score of the tile goes to slot (i, row) of the query's list; masked rows as 0
+                    if (q < nq) {
+                        uint64_t* dst = cand3 + (size_t)q * BQ_PERQ + i * 32;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rowbit = (r & 3) + 8 * (r >> 2) + 4 * h;
+                            const bool ok = (rmask >> rowbit) & 1u;
+                            dst[rowbit] = ok ? (((uint64_t)lbh_ord32(acc[r]) << 32) | (uint32_t)(row0 + rowbit)) : 0ull;
+                        }
+                    }
+                } else {
+                    float m = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+                    for (int r = 3; r < 15; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, acc[r]), acc[r + 1]);
+                    m = __builtin_fmaxf(m, acc[15]);
+                    const bool lanehit = m >= thr[g];
+                    if (__any(lanehit))  // rare: some query of this group has a row at or above its threshold
+                        cnt = k3t_harvest<SINCE, TAGS>(acc, thr[g], lanehit, q, row0, n, ix.created, ix.tags, since_ms, tag_mask, se, sq,
+                                                       cnt, cand3, qtotal);
+                }
+            }
+        }
     };
 
-    // Software pipeline over super-tiles, one barrier each.  During iteration `it` a wave
-    //   1. issues the LDS reads of super-tile it+1's operands into the OTHER fragment set (that tile was staged during
-    //      iteration it-1 and is complete since the last barrier),
-    //   2. stages super-tile it+2 (global loads issued two iterations ago) into the third LDS buffer, whose last readers
-    //      finished before the last barrier, and issues the loads of super-tile it+4,
-    //   3. runs the 8 MFMAs of super-tile it on the fragment set read one iteration ago, then the threshold test.
-    // So the LDS read phase (64 KiB per super-tile and CU, ~0.25 us) overlaps the matrix phase (~0.2 us) instead of
-    // preceding it; with two buffers and one fragment set they alternated and a super-tile took ~0.6 us.
-    f16x8 fa[2][2][4];  // [set][32-claim tile][k-step]
-    f32x4 n0[2], n1[2];  // staged global loads: n?[it & 1] holds super-tile it+2 (fp32 source: two halves).  A second ring
-                         // level (four super-tiles in flight, m -> n register moves) was slower: 515 vs 449 us full pass
-    if (SRC16) {
-        store16(0, load16(st));
-        store16(1, load16(st + G));
-        n0[0] = load16(st + 2 * G);
-        n0[1] = load16(st + 3 * G);
-        n1[0] = n1[1] = n0[0];
-    } else {
-        store_half(0, 0, load_half(st, 0));
-        store_half(0, 1, load_half(st, 1));
-        store_half(1, 0, load_half(st + G, 0));
-        store_half(1, 1, load_half(st + G, 1));
-        n0[0] = load_half(st + 2 * G, 0); n1[0] = load_half(st + 2 * G, 1);
-        n0[1] = load_half(st + 3 * G, 0); n1[1] = load_half(st + 3 * G, 1);
+    // tiles in flight per wave: the ring is unrolled by hand so that every register set has a static name
+#if K3T_RING == 3
+    f32x4 a0[4], a1[4], a2[4];
+    load_tile(a0, i0);
+    load_tile(a1, i0 + W);
+    for (int64_t i = i0; i < n_sel; i += 3 * W) {
+        load_tile(a2, i + 2 * W);
+        process(a0, i);
+        if (i + W < n_sel) {
+            load_tile(a0, i + 3 * W);
+            process(a1, i + W);
+        }
+        if (i + 2 * W < n_sel) {
+            load_tile(a1, i + 4 * W);
+            process(a2, i + 2 * W);
+        }
     }
-    __syncthreads();
-#if LBH_BQ_ABLATE == 10
-    t_pro = wall_clock64();
-#endif
-    int b_cur = 0, b_nxt = 1, b_stg = 2;
-    if (wave_active) {
-        const char* p0 = reinterpret_cast<const char*>(tile + j * TS16) + 16 * h;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) fa[0][0][s] = *reinterpret_cast<const f16x8*>(p0 + 32 * s);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) fa[0][1][s] = *reinterpret_cast<const f16x8*>(p0 + 32 * TS16 * 4 + 32 * s);
-    }
-    while (st < n_super) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            if (st >= n_super) break;
-            if (wave_active) {  // lane (j, h), k-step s: one ds_read_b128 at byte 32s + 16h of row j
-                const char* p0 = reinterpret_cast<const char*>(tile + (size_t)b_nxt * TILE16 + j * TS16) + 16 * h;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) fa[p ^ 1][0][s] = *reinterpret_cast<const f16x8*>(p0 + 32 * s);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) fa[p ^ 1][1][s] = *reinterpret_cast<const f16x8*>(p0 + 32 * TS16 * 4 + 32 * s);
-            }
-            if (SRC16) {
-                store16(b_stg, n0[p]);
-                n0[p] = load16(st + 4 * G);
-            } else {
-                store_half(b_stg, 0, n0[p]);
-                store_half(b_stg, 1, n1[p]);
-                n0[p] = load_half(st + 4 * G, 0);
-                n1[p] = load_half(st + 4 * G, 1);
-            }
-            if (wave_active) {
-                const int64_t row0 = row_begin + st * 64;
-                f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                f32x16 acc1 = acc0;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[p][0][s], bq[s], acc0, 0, 0, 0);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[p][1][s], bq[s], acc1, 0, 0, 0);
-#if LBH_BQ_ABLATE >= 2 && LBH_BQ_ABLATE != 3 && LBH_BQ_ABLATE < 10  // timing-only builds: no epilogue
-                asm volatile("" ::"v"(acc0), "v"(acc1));
-#elif LBH_BQ_ABLATE == 3  // timing-only build: the threshold test alone, candidates are dropped
-                if (__any(lane_hit(acc0) | lane_hit(acc1))) asm volatile("s_nop 0");
 #else
-                // one wave-wide test for both tiles; the row masks are only built for a tile that has a candidate
-                // (without filters and inside the matrix they are all ones)
-                const bool h0 = lane_hit(acc0), h1 = lane_hit(acc1);
-                if (__any(h0 | h1)) {
-                    const bool plain = !SINCE && !TAGS && row0 + 64 <= n;
-                    if (__any(h0)) harvest(acc0, row0, plain ? 0xFFFFFFFFu : row_mask(row0), h0);
-                    if (__any(h1)) harvest(acc1, row0 + 32, plain ? 0xFFFFFFFFu : row_mask(row0 + 32), h1);
-                }
-#endif
-            }
-            __syncthreads();
-            const int t = b_cur;
-            b_cur = b_nxt; b_nxt = b_stg; b_stg = t;
-            st += G;
+    f32x4 a0[4], a1[4];
+    load_tile(a0, i0);
+    for (int64_t i = i0; i < n_sel; i += 2 * W) {
+        load_tile(a1, i + W);
+        process(a0, i);
+        if (i + W < n_sel) {
+            load_tile(a0, i + 2 * W);
+            process(a1, i + W);
         }
     }
-#if LBH_BQ_ABLATE == 10
-    t_loop = wall_clock64();
 #endif
-    // flush: final cut per query, then append to the query's flat candidate list in HBM
-    if (wave_active) {
-        bq_compact_all(bc, __ballot(lane < 32 && qactive && qcnt[myq] > 0));
-        int mycnt = 0, mybase = 0;
-        if (lane < 32 && qactive) {
-            mycnt = qcnt[myq] < BQ_CAP ? qcnt[myq] : BQ_CAP;
-            if (mycnt) {
-                mybase = atomicAdd(&qtotal[myq], mycnt) & (BQ_OVER - 1);
-                if (mybase + mycnt > BQ_PERQ) {
-                    atomicOr(&qtotal[myq], BQ_OVER);
-                    mycnt = 0;
-                }
-            }
-        }
-        for (int qi = 0; qi < 32 && wave * 32 + qi < nq; ++qi) {
-            const int q = wave * 32 + qi;
-            const int cnt = __shfl(mycnt, qi), base = __shfl(mybase, qi);
-            if (lane < cnt) cand3[(size_t)q * BQ_PERQ + base + lane] = qbuf[(size_t)q * BQ_CAP + lane];
-        }
-    }
-#if LBH_BQ_ABLATE == 10
-    if (tid == 0) {  // slot: 0 = unseeded sample pass, 1 = seeded sample pass, 2 = full pass
-        const int slot = seed == nullptr ? 0 : (row_end >= ix.n ? 2 : 1);
-        lbh_k3_dbg[slot][blockIdx.x][0] = t_start;
-        lbh_k3_dbg[slot][blockIdx.x][1] = wall_clock64();
-        lbh_k3_dbg[slot][blockIdx.x][2] = t_pro;
-        lbh_k3_dbg[slot][blockIdx.x][3] = t_pro;
-        lbh_k3_dbg[slot][blockIdx.x][4] = t_loop;
-    }
-#endif
+    if (!DENSE && cnt > 0) k3t_flush(se, sq, cnt, lane, cand3, qtotal);
 }
 
 // Per-query seed threshold from the sample pass: (k-th best fp32 score of the sample) - margin.  The
 // sample is a subset of the corpus, so this never exceeds the final cut (global k-th - margin).
+// dense > 0: the list holds exactly `dense` slots written by a DENSE pass (masked rows as 0, which sorts below every score).
 __global__ __launch_bounds__(SEL_THREADS) void seed_batched_kernel(int k, float margin, const uint64_t* __restrict__ cand3,
                                                                     int32_t* __restrict__ qtotal,
-                                                                    uint32_t* __restrict__ seed) {
+                                                                    uint32_t* __restrict__ seed, int dense) {
     __shared__ int hist[256];
     __shared__ int64_t sh_krem;
     __shared__ int sh_bin;
     const int q = blockIdx.x;
     const int raw = qtotal[q];
-    int E = raw & (BQ_OVER - 1);
+    int E = dense > 0 ? dense : (raw & (BQ_OVER - 1));
     if (E > BQ_PERQ) E = BQ_PERQ;
     const uint64_t* cand = cand3 + (size_t)q * BQ_PERQ;
     uint32_t thr = 0;
@@ -1267,7 +1272,7 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_batched_kernel(int k, float 
             return true;
         };
         const uint32_t kth = (uint32_t)block_radix_select(E, 4, k, val, hist, &sh_krem, &sh_bin);
-        thr = lbh_ord32(lbh_unord32(kth) - margin);
+        thr = kth ? lbh_ord32(lbh_unord32(kth) - margin) : 0u;  // kth == 0: fewer than k real scores in the sample
     }
     __syncthreads();
     if (threadIdx.x == 0) { seed[q] = thr; qtotal[q] = raw & BQ_OVER; }
@@ -1918,6 +1923,67 @@ hipError_t lbh_launch_search_noalloc(void* scratch_ptr, const lbh_dev_index& ix,
     return hipGetLastError();
 }
 
+// K3, fp16: the pass schedule described above scan_batched_tiled_kernel.
+static hipError_t launch_batched_tiled(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, int nq, int k, int has_since,
+                                       int64_t since_ms, uint64_t tag_mask, int n_cu, float margin, hipStream_t s, hipEvent_t ev0,
+                                       hipEvent_t ev1) {
+    hipError_t e = hipMemsetAsync(ws.flags, 0, 16, s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws.bq_total, 0, BQ_MAXQ * 4, s);
+    if (e != hipSuccess) return e;
+    const f32x4* mat = reinterpret_cast<const f32x4*>(emb16);
+    const f32x4* bfrag = reinterpret_cast<const f32x4*>(ws.bq_bfrag);
+    prep_bfrag_kernel<<<(nq + 31) / 32, 256, 0, s>>>(ws.bq_qmat, nq, reinterpret_cast<f16x8*>(ws.bq_bfrag));
+    const int64_t T = (ix.n + 31) / 32;
+    auto launch = [&](int64_t n_sel, const uint32_t* seed, bool dense) {
+        // selected tile i = (i * T) / n_sel in 32.32 fixed point, rounded down so that it never passes T - 1
+        const uint64_t step = n_sel >= T ? (1ull << 32) : (uint64_t)(((unsigned __int128)(uint64_t)T << 32) / (uint64_t)n_sel);
+        int64_t blocks = (n_sel + K3T_WAVES - 1) / K3T_WAVES;
+        if (blocks > 2 * (int64_t)n_cu) blocks = 2 * (int64_t)n_cu;
+        const dim3 g((unsigned)blocks), b(K3T_THREADS);
+#define LBH_TSCAN_ARGS ix, mat, bfrag, nq, since_ms, tag_mask, T, n_sel, step, seed, ws.bq_cand, ws.bq_total
+        if (dense) {
+            if (has_since && tag_mask) scan_batched_tiled_kernel<true, true, true><<<g, b, 0, s>>>(LBH_TSCAN_ARGS);
+            else if (has_since) scan_batched_tiled_kernel<true, false, true><<<g, b, 0, s>>>(LBH_TSCAN_ARGS);
+            else if (tag_mask) scan_batched_tiled_kernel<false, true, true><<<g, b, 0, s>>>(LBH_TSCAN_ARGS);
+            else scan_batched_tiled_kernel<false, false, true><<<g, b, 0, s>>>(LBH_TSCAN_ARGS);
+        } else {
+            if (has_since && tag_mask) scan_batched_tiled_kernel<true, true, false><<<g, b, 0, s>>>(LBH_TSCAN_ARGS);
+            else if (has_since) scan_batched_tiled_kernel<true, false, false><<<g, b, 0, s>>>(LBH_TSCAN_ARGS);
+            else if (tag_mask) scan_batched_tiled_kernel<false, true, false><<<g, b, 0, s>>>(LBH_TSCAN_ARGS);
+            else scan_batched_tiled_kernel<false, false, false><<<g, b, 0, s>>>(LBH_TSCAN_ARGS);
+        }
+#undef LBH_TSCAN_ARGS
+    };
+    if (ev0) (void)hipEventRecord(ev0, s);
+    const uint32_t* seed = nullptr;
+    if (ix.n > BQ_PERQ) {
+        // growth factor between passes: about k * R rows lie above the k-th best of a 1/R subset; keep that near 2048
+        const double r_max = k >= 512 ? 4.0 : 2048.0 / (double)k;
+        const double ratio = (double)T / (double)K3T_DENSE_TILES;
+        int levels = 1;
+        while (std::pow(r_max, (double)levels) < ratio) ++levels;
+        const double r = std::pow(ratio, 1.0 / (double)levels);
+        launch(K3T_DENSE_TILES, nullptr, true);
+        seed_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(k, margin, ws.bq_cand, ws.bq_total, ws.bq_seed, K3T_DENSE_TILES * 32);
+        seed = ws.bq_seed;
+        double sel = (double)K3T_DENSE_TILES;
+        for (int l = 1; l < levels; ++l) {
+            sel *= r;
+            int64_t n_sel = (int64_t)sel;
+            if (n_sel >= T) break;
+            launch(n_sel, seed, false);
+            seed_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(k, margin, ws.bq_cand, ws.bq_total, ws.bq_seed, 0);
+        }
+    }
+    launch(T, seed, false);  // seed == nullptr (a corpus that fits the lists): every live row of every query is listed
+    if (ev1) (void)hipEventRecord(ev1, s);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    select_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(ix, ws.bq_qmat, k, margin, ws.bq_cand, ws.bq_total, ws.flags, ws.bq_result_dev);
+    return hipGetLastError();
+}
+
 hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, int nq, int k, int has_since,
                                      int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, float norm_scale, hipStream_t s,
                                      hipEvent_t ev0, hipEvent_t ev1) {
@@ -1930,11 +1996,7 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* em
         const void* fns[] = {(const void*)scan_batched_kernel<true, true, false>, (const void*)scan_batched_kernel<true, false, false>,
                              (const void*)scan_batched_kernel<false, true, false>, (const void*)scan_batched_kernel<false, false, false>,
                              (const void*)scan_batched_kernel<true, true, true>, (const void*)scan_batched_kernel<true, false, true>,
-                             (const void*)scan_batched_kernel<false, true, true>, (const void*)scan_batched_kernel<false, false, true>,
-                             (const void*)scan_batched_f16_kernel<true, true, false>, (const void*)scan_batched_f16_kernel<true, false, false>,
-                             (const void*)scan_batched_f16_kernel<false, true, false>, (const void*)scan_batched_f16_kernel<false, false, false>,
-                             (const void*)scan_batched_f16_kernel<true, true, true>, (const void*)scan_batched_f16_kernel<true, false, true>,
-                             (const void*)scan_batched_f16_kernel<false, true, true>, (const void*)scan_batched_f16_kernel<false, false, true>};
+                             (const void*)scan_batched_kernel<false, true, true>, (const void*)scan_batched_kernel<false, false, true>};
         for (const void* f : fns) {
             const hipError_t e1 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BQ_LDS);
             if (e1 != hipSuccess) once_err = e1;
@@ -1953,9 +2015,11 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* em
     if (once_err != hipSuccess) return once_err;
     hipError_t e;
     // the error bounds are relative to |x||q| (1 for the reference's unit vectors); fp16 additionally needs the
-    // components inside its range, so anything but unit-scale data takes the split-bf16 kernel instead
-    if (bf16 == 2 && (norm_scale > 1.001f || norm_scale < 0.25f)) bf16 = 1;
-    const float margin = (bf16 == 2 ? LBH_MARGIN_F16 : bf16 ? LBH_MARGIN_BF16X3 : LBH_MARGIN) * norm_scale;
+    // components inside its range, so anything but unit-scale data takes the split-bf16 kernel instead (the caller
+    // passes the fp16 copy only for unit-scale data)
+    if (bf16 == 2 && (!emb16 || norm_scale > 1.001f || norm_scale < 0.25f)) bf16 = 1;
+    if (bf16 == 2) return launch_batched_tiled(ix, emb16, ws, nq, k, has_since, since_ms, tag_mask, n_cu, LBH_MARGIN_F16 * norm_scale, s, ev0, ev1);
+    const float margin = (bf16 ? LBH_MARGIN_BF16X3 : LBH_MARGIN) * norm_scale;
     e = hipMemsetAsync(ws.flags, 0, 16, s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws.bq_total, 0, BQ_MAXQ * 4, s);
@@ -1965,17 +2029,7 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* em
         const int64_t tiles = (r1 - r0 + 63) / 64;
         const dim3 g((unsigned)(tiles < n_cu ? tiles : n_cu));
 #define LBH_BSCAN_ARGS ws.bq_qmat, nq, k, margin, since_ms, tag_mask, r0, r1, seed, ws.bq_cand, ws.bq_total, ws.flags
-        if (bf16 == 2 && emb16) {  // one fp16 product per k-step, operands streamed from the fp16 copy
-            if (has_since && tag_mask) scan_batched_f16_kernel<true, true, true><<<g, b, BQ_LDS, s>>>(ix, emb16, LBH_BSCAN_ARGS);
-            else if (has_since) scan_batched_f16_kernel<true, false, true><<<g, b, BQ_LDS, s>>>(ix, emb16, LBH_BSCAN_ARGS);
-            else if (tag_mask) scan_batched_f16_kernel<false, true, true><<<g, b, BQ_LDS, s>>>(ix, emb16, LBH_BSCAN_ARGS);
-            else scan_batched_f16_kernel<false, false, true><<<g, b, BQ_LDS, s>>>(ix, emb16, LBH_BSCAN_ARGS);
-        } else if (bf16 == 2) {    // one fp16 product per k-step, fp32 matrix converted while staging
-            if (has_since && tag_mask) scan_batched_f16_kernel<true, true, false><<<g, b, BQ_LDS, s>>>(ix, nullptr, LBH_BSCAN_ARGS);
-            else if (has_since) scan_batched_f16_kernel<true, false, false><<<g, b, BQ_LDS, s>>>(ix, nullptr, LBH_BSCAN_ARGS);
-            else if (tag_mask) scan_batched_f16_kernel<false, true, false><<<g, b, BQ_LDS, s>>>(ix, nullptr, LBH_BSCAN_ARGS);
-            else scan_batched_f16_kernel<false, false, false><<<g, b, BQ_LDS, s>>>(ix, nullptr, LBH_BSCAN_ARGS);
-        } else if (bf16) {  // split-bf16 products on v_mfma_f32_32x32x16_bf16
+        if (bf16) {  // split-bf16 products on v_mfma_f32_32x32x16_bf16
             if (has_since && tag_mask) scan_batched_kernel<true, true, true><<<g, b, BQ_LDS, s>>>(ix, LBH_BSCAN_ARGS);
             else if (has_since) scan_batched_kernel<true, false, true><<<g, b, BQ_LDS, s>>>(ix, LBH_BSCAN_ARGS);
             else if (tag_mask) scan_batched_kernel<false, true, true><<<g, b, BQ_LDS, s>>>(ix, LBH_BSCAN_ARGS);
@@ -1999,7 +2053,7 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* em
         const int64_t ns = ((ix.n >> shifts[i]) / 64) * 64;
         if (ns < 16384) continue;
         launch(0, ns, seed);
-        seed_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(k, margin, ws.bq_cand, ws.bq_total, ws.bq_seed);
+        seed_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(k, margin, ws.bq_cand, ws.bq_total, ws.bq_seed, 0);
         seed = ws.bq_seed;
     }
     launch(0, ix.n, seed);
