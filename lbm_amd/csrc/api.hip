@@ -375,7 +375,7 @@ int ensure_batched_ws(lbh_index* ix) {
     if (w.bq_qmat) return LBH_OK;
     HIP_TRY(hipMalloc((void**)&w.bq_qmat, (size_t)LBH_BQ_MAXQ * 512));
     HIP_TRY(hipMalloc((void**)&w.bq_cand, (size_t)LBH_BQ_MAXQ * LBH_BQ_PERQ * 8));
-    HIP_TRY(hipMalloc((void**)&w.bq_total, (size_t)LBH_BQ_MAXQ * 4));
+    HIP_TRY(hipMalloc((void**)&w.bq_total, (size_t)LBH_BQ_MAXQ * LBH_BQ_QT_STRIDE * 4));
     HIP_TRY(hipMalloc((void**)&w.bq_seed, (size_t)LBH_BQ_MAXQ * 4));
     HIP_TRY(hipMalloc((void**)&w.bq_bfrag, (size_t)LBH_BQ_MAXQ * 128));
     HIP_TRY(hipHostMalloc((void**)&w.bq_result_host, sizeof(lbh_result) * LBH_BQ_MAXQ, hipHostMallocMapped));

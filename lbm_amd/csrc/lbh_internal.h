@@ -14,6 +14,7 @@
 #define LBH_MCAP 2048                           // max rows the single-block final stage sorts exactly
 #define LBH_BQ_MAXQ 256                         // queries per batched (MFMA) launch
 #define LBH_BQ_PERQ 8192                        // candidate slots per query of a batched launch
+#define LBH_BQ_QT_STRIDE 32                     // ints between two queries' list counters (one cache line each)
 #define LBH_BQ_KMAX 16                          // largest top_k the batched path serves
 #define LBH_MAX_BLOCKS 2048                     // max scan grid (lists in the workspace)
 
@@ -119,7 +120,7 @@ struct lbh_workspace {
     // batched (K3) workspace, allocated on first use
     double* bq_qmat;          // 256 x 64 fp64 query matrix
     uint64_t* bq_cand;        // 256 x LBH_BQ_PERQ flat candidate lists, one per query
-    int32_t* bq_total;        // 256 counters
+    int32_t* bq_total;        // 256 counters, LBH_BQ_QT_STRIDE ints apart
     uint32_t* bq_seed;        // 256 per-query seed thresholds (ord32) from the sample pass
     void* bq_bfrag;           // 32 KiB: the queries as fp16 MFMA B fragments (scan_batched_tiled_kernel)
     lbh_result* bq_result_host;  // 256 results, pinned + device-mapped

@@ -580,6 +580,10 @@ constexpr int BQ_THREADS = 512, BQ_MAXQ = 256, BQ_CAP = 56, BQ_TRIG = 24;
 constexpr int BQ_TS = 68, BQ_TILE_F = 64 * BQ_TS, BQ_NBUF = 2;
 constexpr int BQ_OVER = 0x40000000;  // bit of a query's counter: its candidate set could not be bounded here
 constexpr int BQ_PERQ = 8192;  // candidate slots per query in HBM (256 workgroups x 32)
+// Stride (in ints) between the per-query list counters: one 128-byte line each.  Packed into 1 KiB, the ~72 k appends of
+// a 256-query pass were atomics on EIGHT cache lines and serialised there (about 11 ns each: 75 us per pass, whatever
+// the kernel around them did); a line per query leaves ~280 per line.
+constexpr int BQ_QT = LBH_BQ_QT_STRIDE;
 constexpr size_t BQ_LDS = (size_t)BQ_MAXQ * BQ_CAP * 8 + BQ_NBUF * BQ_TILE_F * 4 + BQ_MAXQ * 4 * 2;  // 151,552 B
 
 struct bq_ctx {          // per-wave view of the K3 candidate state (LDS) for the out-of-line slow path
@@ -620,7 +624,7 @@ __device__ __forceinline__ void bq_compact_impl(const bq_ctx& c, int q) {
     if (lane == 0) {
         c.qcnt[q] = newcnt;
         c.qthr[q] = t2;
-        if (newcnt > BQ_TRIG) atomicOr(&c.qtotal[q], BQ_OVER);  // too many near-ties for this path: that query only
+        if (newcnt > BQ_TRIG) atomicOr(&c.qtotal[q * BQ_QT], BQ_OVER);  // too many near-ties for this path: that query only
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -687,7 +691,7 @@ __device__ __forceinline__ void bq_compact_all_impl(const bq_ctx& c, uint64_t ne
         }
         c.qcnt[q] = newcnt;
         c.qthr[q] = t2;
-        if (newcnt > BQ_TRIG) atomicOr(&c.qtotal[q], BQ_OVER);  // too many near-ties for this path: that query only
+        if (newcnt > BQ_TRIG) atomicOr(&c.qtotal[q * BQ_QT], BQ_OVER);  // too many near-ties for this path: that query only
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -712,7 +716,7 @@ __device__ __forceinline__ uint32_t bq_harvest_impl(const bq_ctx& c, const f32x1
             if (pass) {
                 const int pos = atomicAdd(&c.qcnt[c.myq], 1);
                 if (pos < BQ_CAP) c.qbuf[(size_t)c.myq * BQ_CAP + pos] = ((uint64_t)o << 32) | (uint32_t)(row0 + rowbit);
-                else atomicOr(&c.qtotal[c.myq], BQ_OVER);
+                else atomicOr(&c.qtotal[c.myq * BQ_QT], BQ_OVER);
             }
         }
     }
@@ -749,7 +753,7 @@ __device__ __forceinline__ uint32_t bq_harvest_lanes(const bq_ctx& c, const f32x
             if (((rowmask >> rowbit) & 1u) && o >= thr) {
                 const int pos = atomicAdd(&c.qcnt[c.myq], 1);
                 if (pos < BQ_CAP) c.qbuf[(size_t)c.myq * BQ_CAP + pos] = ((uint64_t)o << 32) | (uint32_t)(row0 + rowbit);
-                else atomicOr(&c.qtotal[c.myq], BQ_OVER);
+                else atomicOr(&c.qtotal[c.myq * BQ_QT], BQ_OVER);
                 last = pos;
             }
         }
@@ -996,9 +1000,9 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
         if (lane < 32 && qactive) {
             mycnt = qcnt[myq] < BQ_CAP ? qcnt[myq] : BQ_CAP;
             if (mycnt) {
-                mybase = atomicAdd(&qtotal[myq], mycnt) & (BQ_OVER - 1);
+                mybase = atomicAdd(&qtotal[myq * BQ_QT], mycnt) & (BQ_OVER - 1);
                 if (mybase + mycnt > BQ_PERQ) {
-                    atomicOr(&qtotal[myq], BQ_OVER);
+                    atomicOr(&qtotal[myq * BQ_QT], BQ_OVER);
                     mycnt = 0;
                 }
             }
@@ -1046,12 +1050,18 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr int K3T_THREADS = 256;    // 4 waves; two workgroups per CU = two waves per SIMD, 256 VGPRs each
+#ifndef K3T_THREADS
+#define K3T_THREADS 512             // workgroup of the scan kernel (its waves share the LDS image of the queries)
+#endif
+#ifndef K3T_BLOCKS_PER_CU
+#define K3T_BLOCKS_PER_CU 2
+#endif
 constexpr int K3T_WAVES = K3T_THREADS / 64;
 constexpr int K3T_STAGE = 256;      // per-wave staging list (entries)
 #ifndef K3T_RING
-#define K3T_RING 3                  // claim tiles in flight per wave (register sets)
+#define K3T_RING 2                  // claim tiles in flight per wave (register sets of 16 VGPRs)
 #endif
+#define K3T_WPS (K3T_BLOCKS_PER_CU * K3T_THREADS / 256)  // waves per SIMD the register budget is sized for
 constexpr int K3T_DENSE_TILES = BQ_PERQ / 32;  // tiles whose every score fits a query's list
 
 // B operand image: [group g][k-step s][lane] x 16 B = dims 16 s + 8 h .. + 7 of query 32 g + j as fp16 (one rounding
@@ -1071,9 +1081,9 @@ __device__ __forceinline__ void k3t_flush(const uint64_t* se, const uint16_t* sq
     for (int i = lane; i < cnt; i += 64) {
         const uint64_t e = se[i];
         const int q = sq[i];
-        const int pos = atomicAdd(&qtotal[q], 1) & (BQ_OVER - 1);
+        const int pos = atomicAdd(&qtotal[q * BQ_QT], 1) & (BQ_OVER - 1);
         if (pos < BQ_PERQ) cand3[(size_t)q * BQ_PERQ + pos] = e;
-        else atomicOr(&qtotal[q], BQ_OVER);  // more near-candidates than the list holds: that query is re-run alone
+        else atomicOr(&qtotal[q * BQ_QT], BQ_OVER);  // more near-candidates than the list holds: that query is re-run alone
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -1082,76 +1092,100 @@ __device__ __forceinline__ void k3t_flush(const uint64_t* se, const uint16_t* sq
 // slots x 8 query groups); with this code inlined into each of them the loop body was 290 KB of instructions, the fast
 // path hopped from one instruction-cache miss to the next and the full pass ran 3x slower than the round-1 kernel.  One
 // shared copy stays resident.  Returns the new fill of the wave's staging list.
-template <bool SINCE, bool TAGS>
-__device__ __noinline__ int k3t_harvest(f32x16 acc, float thr, bool lanehit, int q, int64_t row0, int64_t n,
+#ifndef K3T_INLINE_HARVEST
+#define K3T_INLINE_HARVEST 0
+#endif
+#if K3T_INLINE_HARVEST
+__device__ __forceinline__
+#else
+__device__ __noinline__
+#endif
+int k3t_harvest(f32x16 acc, float thr, bool lanehit, int q, int64_t row0, int64_t n,
                                         const int64_t* __restrict__ created, const uint64_t* __restrict__ tags,
-                                        int64_t since_ms, uint64_t tag_mask, uint64_t* se, uint16_t* sq, int cnt,
+                                        int has_since, int64_t since_ms, uint64_t tag_mask, uint64_t* se, uint16_t* sq, int cnt,
                                         uint64_t* __restrict__ cand3, int32_t* __restrict__ qtotal) {
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     uint32_t rmask = 0xFFFFFFFFu;  // rows of the tile that exist and pass the since / tag filters
-    if (SINCE || TAGS || row0 + 32 > n) {
+    if (has_since || tag_mask || row0 + 32 > n) {
         bool rv = false;
         if (lane < 32) {
             const int64_t r = row0 + lane;
             rv = r < n;
-            if (SINCE) rv = rv && created[rv ? r : 0] >= since_ms;
-            if (TAGS) rv = rv && (tags[r < n ? r : 0] & tag_mask) != 0;
+            if (has_since) rv = rv && created[rv ? r : 0] >= since_ms;
+            if (tag_mask) rv = rv && (tags[r < n ? r : 0] & tag_mask) != 0;
         }
         rmask = (uint32_t)__ballot(rv);
     }
+    // which of the lane's 16 rows pass (bit r), then one ballot per register that has any
+    uint32_t bits = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rowbit = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const bool pass = lanehit && acc[r] >= thr && ((rmask >> rowbit) & 1u);
+        bits |= (lanehit && acc[r] >= thr && ((rmask >> rowbit) & 1u)) ? (1u << r) : 0u;
+    }
+    uint32_t any_bits = bits;  // OR over the wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) any_bits |= (uint32_t)__shfl_xor((int)any_bits, off);
+    any_bits = __builtin_amdgcn_readfirstlane(any_bits);
+    if (any_bits && cnt + __popcll(__ballot(bits != 0)) * 16 > K3T_STAGE) {  // room for the worst case of this call
+        k3t_flush(se, sq, cnt, lane, cand3, qtotal);
+        cnt = 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (!((any_bits >> r) & 1u)) continue;  // wave-uniform
+        const int rowbit = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool pass = (bits >> r) & 1u;
         const uint64_t pm = __ballot(pass);
-        if (pm) {
-            if (cnt + 64 > K3T_STAGE) {
-                k3t_flush(se, sq, cnt, lane, cand3, qtotal);
-                cnt = 0;
-            }
-            if (pass) {
-                const int pos = cnt + __popcll(pm & lt_mask);
-                se[pos] = ((uint64_t)lbh_ord32(acc[r]) << 32) | (uint32_t)(row0 + rowbit);
-                sq[pos] = (uint16_t)q;
-            }
-            cnt += __popcll(pm);
+        if (cnt + 64 > K3T_STAGE) {  // a flood (cold thresholds): flush between registers
+            k3t_flush(se, sq, cnt, lane, cand3, qtotal);
+            cnt = 0;
         }
+        if (pass) {
+            const int pos = cnt + __popcll(pm & lt_mask);
+            se[pos] = ((uint64_t)lbh_ord32(acc[r]) << 32) | (uint32_t)(row0 + rowbit);
+            sq[pos] = (uint16_t)q;
+        }
+        cnt += __popcll(pm);
     }
     __builtin_amdgcn_wave_barrier();
     return cnt;
 }
 
-template <bool SINCE, bool TAGS, bool DENSE>
-__global__ __launch_bounds__(K3T_THREADS, 2) void scan_batched_tiled_kernel(
-    lbh_dev_index ix, const f32x4* __restrict__ emb16t, const f32x4* __restrict__ bfrag, int nq, int64_t since_ms,
+// The scan kernel.  Workgroup = K3T_THREADS threads; its waves share one read-only LDS image of the queries (B fragments
+// of all groups, 32 KiB, plus the 256 thresholds) filled once in the prologue -- the only barrier of the kernel.  Keeping
+// the 128 VGPRs of B fragments in registers instead left room for two waves per SIMD at best, with spills next to the
+// tile ring; a wave alone on its SIMD cannot issue the epilogue's vector instructions fast enough (4 cycles each instead
+// of 2) and, with the accumulators in AGPRs, needs 16 extra moves per block (measured: 456-490 us for the full pass
+// against 379 us at two waves per SIMD).  From LDS a group's B fragments cost four conflict-free ds_read_b128 per 32 x 32
+// block (a third of the LDS bandwidth when the matrix pipes are saturated), are prefetched one group ahead, and a wave
+// needs ~110 registers, so K3T_WPS waves per SIMD overlap one wave's MFMAs with the others' epilogues and loads.
+__global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kernel(
+    lbh_dev_index ix, const f32x4* __restrict__ emb16t, const f32x4* __restrict__ bfrag, int nq, int has_since, int64_t since_ms,
     uint64_t tag_mask, int64_t n_tiles, int64_t n_sel, uint64_t step_q32, const uint32_t* __restrict__ seed,
     uint64_t* __restrict__ cand3, int32_t* __restrict__ qtotal) {
+    __shared__ f32x4 ldsb[8 * 4 * 64];  // [group][k-step][lane] x 16 B
+    __shared__ float ldsthr[BQ_MAXQ];
     __shared__ uint64_t stage_e[K3T_WAVES][K3T_STAGE];
     __shared__ uint16_t stage_q[K3T_WAVES][K3T_STAGE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31;
     const int ngroups = (nq + 31) >> 5;
     const int64_t n = ix.n;
     uint64_t* se = stage_e[wave];
     uint16_t* sq = stage_q[wave];
     int cnt = 0;
 
-    // B fragments of every query group, resident for the whole launch
-    f16x8 bq[8][4];
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) bq[g][s] = __builtin_bit_cast(f16x8, bfrag[(g * 4 + s) * 64 + lane]);
-    }
-    // fixed thresholds of this lane's query in every group (+inf for a query slot that is not in use)
-    float thr[8];
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        const int q = 32 * g + j;
+    for (int i = tid; i < ngroups * 256; i += K3T_THREADS) ldsb[i] = bfrag[i];
+    for (int q = tid; q < BQ_MAXQ; q += K3T_THREADS) {
         const uint32_t o = (seed && q < nq) ? seed[q] : 0u;
-        thr[g] = q < nq ? (o ? lbh_unord32(o) : -__builtin_inff()) : __builtin_inff();
+        ldsthr[q] = q < nq ? (o ? lbh_unord32(o) : -__builtin_inff()) : __builtin_inff();
+#ifdef K3T_NOHIT  // timing-only build: no row ever reaches a threshold (what the scan costs without the harvest path)
+        ldsthr[q] = __builtin_inff();
+#endif
     }
+    __syncthreads();
 
     // the i-th selected tile: tiles spread evenly over the index ((i * n_tiles) / n_sel in 32.32 fixed point; distinct
     // for distinct i because the step is >= 1)
@@ -1165,90 +1199,108 @@ __global__ __launch_bounds__(K3T_THREADS, 2) void scan_batched_tiled_kernel(
 #pragma unroll
         for (int s = 0; s < 4; ++s) a[s] = __builtin_nontemporal_load(p + s * 64);
     };
-    auto row_mask = [&](int64_t row0) -> uint32_t {  // rows of the tile that exist and pass the since / tag filters
-        bool rv = false;
-        if (lane < 32) {
-            const int64_t r = row0 + lane;
-            rv = r < n;
-            if (SINCE) rv = rv && ix.created[rv ? r : 0] >= since_ms;
-            if (TAGS) rv = rv && (ix.tags[r < n ? r : 0] & tag_mask) != 0;
-        }
-        return (uint32_t)__ballot(rv);
+    auto load_b = [&](f32x4 (&b)[4], int g) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[s] = ldsb[(g * 4 + s) * 64 + lane];
+    };
+    // one 32 x 32 block: 4 MFMAs, lane maximum as a 3-level tree of v_max3_f32, one compare, one wave vote
+    auto block = [&](const f32x4 (&araw)[4], const f32x4 (&braw)[4], int g, int64_t row0) {
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, araw[s]), __builtin_bit_cast(f16x8, braw[s]), acc, 0, 0, 0);
+        const float thr = ldsthr[g * 32 + j];
+        const float m0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
+        const float m1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
+        const float m2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]);
+        const float m3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
+        const float m4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
+        const float m5 = __builtin_fmaxf(__builtin_fmaxf(m0, m1), m2);
+        const float m6 = __builtin_fmaxf(__builtin_fmaxf(m3, m4), acc[15]);
+        const bool lanehit = __builtin_fmaxf(m5, m6) >= thr;
+        if (__any(lanehit))  // rare: some query of this group has a row at or above its threshold
+            cnt = k3t_harvest(acc, thr, lanehit, 32 * g + j, row0, n, ix.created, ix.tags, has_since, since_ms, tag_mask, se, sq,
+                              cnt, cand3, qtotal);
     };
 
     const int64_t W = (int64_t)gridDim.x * K3T_WAVES;
     const int64_t i0 = (int64_t)blockIdx.x * K3T_WAVES + wave;
 
+    // one tile against every query group; the next group's B fragments are read from LDS while this group's MFMAs run
+    // (two register sets, ping-pong; after the last group the prefetch wraps to group 0 for the next tile)
+    f32x4 b0[4], b1[4];
+    load_b(b0, 0);
     auto process = [&](const f32x4 (&araw)[4], int64_t i) {
-        const int64_t tile = tile_of(i);
-        const int64_t row0 = tile * 32;
-        f16x8 a[4];
+        const int64_t row0 = tile_of(i) * 32;
+        for (int g = 0; g < ngroups; g += 2) {
+            load_b(b1, g + 1 < ngroups ? g + 1 : 0);
+            block(araw, b0, g, row0);
+            if (g + 1 < ngroups) {
+                load_b(b0, g + 2 < ngroups ? g + 2 : 0);
+                block(araw, b1, g + 1, row0);
+            } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a[s] = __builtin_bit_cast(f16x8, araw[s]);
-        const bool plain = !SINCE && !TAGS && row0 + 32 <= n;
-        uint32_t rmask = 0xFFFFFFFFu;
-        if (DENSE && !plain) rmask = row_mask(row0);
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            if (g < ngroups) {
-                f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[g][s], acc, 0, 0, 0);
-                const int q = 32 * g + j;
-                if (DENSE) {  // every score of the tile goes to slot (i, row) of the query's list; masked rows as 0
-                    if (q < nq) {
-                        uint64_t* dst = cand3 + (size_t)q * BQ_PERQ + i * 32;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int rowbit = (r & 3) + 8 * (r >> 2) + 4 * h;
-                            const bool ok = (rmask >> rowbit) & 1u;
-                            dst[rowbit] = ok ? (((uint64_t)lbh_ord32(acc[r]) << 32) | (uint32_t)(row0 + rowbit)) : 0ull;
-                        }
-                    }
-                } else {
-                    float m = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
-#pragma unroll
-                    for (int r = 3; r < 15; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, acc[r]), acc[r + 1]);
-                    m = __builtin_fmaxf(m, acc[15]);
-                    const bool lanehit = m >= thr[g];
-                    if (__any(lanehit))  // rare: some query of this group has a row at or above its threshold
-                        cnt = k3t_harvest<SINCE, TAGS>(acc, thr[g], lanehit, q, row0, n, ix.created, ix.tags, since_ms, tag_mask, se, sq,
-                                                       cnt, cand3, qtotal);
-                }
+                for (int s = 0; s < 4; ++s) b0[s] = b1[s];  // odd group count: b1 already holds group 0
             }
         }
     };
 
-    // tiles in flight per wave: the ring is unrolled by hand so that every register set has a static name
-#if K3T_RING == 3
-    f32x4 a0[4], a1[4], a2[4];
-    load_tile(a0, i0);
-    load_tile(a1, i0 + W);
-    for (int64_t i = i0; i < n_sel; i += 3 * W) {
-        load_tile(a2, i + 2 * W);
-        process(a0, i);
-        if (i + W < n_sel) {
-            load_tile(a0, i + 3 * W);
-            process(a1, i + W);
-        }
-        if (i + 2 * W < n_sel) {
-            load_tile(a1, i + 4 * W);
-            process(a2, i + 2 * W);
+    // K3T_RING claim tiles in flight per wave.  The ring loop is fully unrolled, so every register set has a static name
+    // (rotating the sets with register moves would make each move wait for the youngest load).
+    f32x4 ring[K3T_RING][4];
+#pragma unroll
+    for (int r = 0; r < K3T_RING - 1; ++r) load_tile(ring[r], i0 + r * W);
+    for (int64_t i = i0; i < n_sel; i += K3T_RING * W) {
+#pragma unroll
+        for (int r = 0; r < K3T_RING; ++r) {
+            if (i + r * W < n_sel) {  // wave-uniform
+                load_tile(ring[(r + K3T_RING - 1) % K3T_RING], i + (r + K3T_RING - 1) * W);
+                process(ring[r], i + r * W);
+            }
         }
     }
-#else
-    f32x4 a0[4], a1[4];
-    load_tile(a0, i0);
-    for (int64_t i = i0; i < n_sel; i += 2 * W) {
-        load_tile(a1, i + W);
-        process(a0, i);
-        if (i + W < n_sel) {
-            load_tile(a0, i + 2 * W);
-            process(a1, i + W);
+    if (cnt > 0) k3t_flush(se, sq, cnt, lane, cand3, qtotal);
+}
+
+// DENSE pass: every score of the selected tiles (at most K3T_DENSE_TILES, one per wave) goes to slot (i, row) of its
+// query's list, rows that do not exist or fail the since / tag filters as 0 (below every real score).
+__global__ __launch_bounds__(256) void scan_batched_dense_kernel(
+    lbh_dev_index ix, const f32x4* __restrict__ emb16t, const f32x4* __restrict__ bfrag, int nq, int has_since, int64_t since_ms,
+    uint64_t tag_mask, int64_t n_tiles, int64_t n_sel, uint64_t step_q32, uint64_t* __restrict__ cand3) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= n_sel) return;
+    int64_t tile = (int64_t)(((unsigned __int128)(uint64_t)i * step_q32) >> 32);
+    tile = tile < n_tiles ? tile : n_tiles - 1;
+    const int64_t row0 = tile * 32, n = ix.n;
+    f16x8 a[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] = __builtin_bit_cast(f16x8, emb16t[tile * 256 + s * 64 + lane]);
+    bool rv = false;
+    if (lane < 32) {
+        const int64_t r = row0 + lane;
+        rv = r < n;
+        if (has_since) rv = rv && ix.created[rv ? r : 0] >= since_ms;
+        if (tag_mask) rv = rv && (ix.tags[r < n ? r : 0] & tag_mask) != 0;
+    }
+    const uint32_t rmask = (uint32_t)__ballot(rv);
+    const int ngroups = (nq + 31) >> 5;
+    for (int g = 0; g < ngroups; ++g) {
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], __builtin_bit_cast(f16x8, bfrag[(g * 4 + s) * 64 + lane]), acc, 0, 0, 0);
+        const int q = 32 * g + j;
+        if (q < nq) {
+            uint64_t* dst = cand3 + (size_t)q * BQ_PERQ + i * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowbit = (r & 3) + 8 * (r >> 2) + 4 * h;
+                dst[rowbit] = ((rmask >> rowbit) & 1u) ? (((uint64_t)lbh_ord32(acc[r]) << 32) | (uint32_t)(row0 + rowbit)) : 0ull;
+            }
         }
     }
-#endif
-    if (!DENSE && cnt > 0) k3t_flush(se, sq, cnt, lane, cand3, qtotal);
 }
 
 // Per-query seed threshold from the sample pass: (k-th best fp32 score of the sample) - margin.  The
@@ -1261,7 +1313,7 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_batched_kernel(int k, float 
     __shared__ int64_t sh_krem;
     __shared__ int sh_bin;
     const int q = blockIdx.x;
-    const int raw = qtotal[q];
+    const int raw = qtotal[q * BQ_QT];
     int E = dense > 0 ? dense : (raw & (BQ_OVER - 1));
     if (E > BQ_PERQ) E = BQ_PERQ;
     const uint64_t* cand = cand3 + (size_t)q * BQ_PERQ;
@@ -1275,7 +1327,7 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_batched_kernel(int k, float 
         thr = kth ? lbh_ord32(lbh_unord32(kth) - margin) : 0u;  // kth == 0: fewer than k real scores in the sample
     }
     __syncthreads();
-    if (threadIdx.x == 0) { seed[q] = thr; qtotal[q] = raw & BQ_OVER; }
+    if (threadIdx.x == 0) { seed[q] = thr; qtotal[q * BQ_QT] = raw & BQ_OVER; }
 }
 
 // K4 for a batch: one block per query.
@@ -1289,7 +1341,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_batched_kernel(lbh_dev_ind
     lbh_result* res = res_arr + q;
     if (tid < 64) qs[tid] = qmat[(size_t)q * 64 + tid];
     __syncthreads();
-    const int raw = qtotal[q];
+    const int raw = qtotal[q * BQ_QT];
     if (flags[0] || (raw & BQ_OVER)) {
         if (tid == 0) { res->count = 0; res->overflow = 1; res->candidates = 0; }
         return;
@@ -1929,31 +1981,24 @@ static hipError_t launch_batched_tiled(const lbh_dev_index& ix, const uint16_t* 
                                        hipEvent_t ev1) {
     hipError_t e = hipMemsetAsync(ws.flags, 0, 16, s);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(ws.bq_total, 0, BQ_MAXQ * 4, s);
+    e = hipMemsetAsync(ws.bq_total, 0, BQ_MAXQ * BQ_QT * 4, s);
     if (e != hipSuccess) return e;
     const f32x4* mat = reinterpret_cast<const f32x4*>(emb16);
     const f32x4* bfrag = reinterpret_cast<const f32x4*>(ws.bq_bfrag);
-    prep_bfrag_kernel<<<(nq + 31) / 32, 256, 0, s>>>(ws.bq_qmat, nq, reinterpret_cast<f16x8*>(ws.bq_bfrag));
+    prep_bfrag_kernel<<<8, 256, 0, s>>>(ws.bq_qmat, nq, reinterpret_cast<f16x8*>(ws.bq_bfrag));  // all 8 groups: unused ones as zeros
     const int64_t T = (ix.n + 31) / 32;
     auto launch = [&](int64_t n_sel, const uint32_t* seed, bool dense) {
         // selected tile i = (i * T) / n_sel in 32.32 fixed point, rounded down so that it never passes T - 1
         const uint64_t step = n_sel >= T ? (1ull << 32) : (uint64_t)(((unsigned __int128)(uint64_t)T << 32) / (uint64_t)n_sel);
-        int64_t blocks = (n_sel + K3T_WAVES - 1) / K3T_WAVES;
-        if (blocks > 2 * (int64_t)n_cu) blocks = 2 * (int64_t)n_cu;
-        const dim3 g((unsigned)blocks), b(K3T_THREADS);
-#define LBH_TSCAN_ARGS ix, mat, bfrag, nq, since_ms, tag_mask, T, n_sel, step, seed, ws.bq_cand, ws.bq_total
         if (dense) {
-            if (has_since && tag_mask) scan_batched_tiled_kernel<true, true, true><<<g, b, 0, s>>>(LBH_TSCAN_ARGS);
-            else if (has_since) scan_batched_tiled_kernel<true, false, true><<<g, b, 0, s>>>(LBH_TSCAN_ARGS);
-            else if (tag_mask) scan_batched_tiled_kernel<false, true, true><<<g, b, 0, s>>>(LBH_TSCAN_ARGS);
-            else scan_batched_tiled_kernel<false, false, true><<<g, b, 0, s>>>(LBH_TSCAN_ARGS);
-        } else {
-            if (has_since && tag_mask) scan_batched_tiled_kernel<true, true, false><<<g, b, 0, s>>>(LBH_TSCAN_ARGS);
-            else if (has_since) scan_batched_tiled_kernel<true, false, false><<<g, b, 0, s>>>(LBH_TSCAN_ARGS);
-            else if (tag_mask) scan_batched_tiled_kernel<false, true, false><<<g, b, 0, s>>>(LBH_TSCAN_ARGS);
-            else scan_batched_tiled_kernel<false, false, false><<<g, b, 0, s>>>(LBH_TSCAN_ARGS);
+            scan_batched_dense_kernel<<<dim3((unsigned)((n_sel + 3) / 4)), 256, 0, s>>>(ix, mat, bfrag, nq, has_since, since_ms, tag_mask, T, n_sel,
+                                                                                      step, ws.bq_cand);
+            return;
         }
-#undef LBH_TSCAN_ARGS
+        int64_t blocks = (n_sel + K3T_WAVES - 1) / K3T_WAVES;
+        if (blocks > K3T_BLOCKS_PER_CU * (int64_t)n_cu) blocks = K3T_BLOCKS_PER_CU * (int64_t)n_cu;
+        scan_batched_tiled_kernel<<<dim3((unsigned)blocks), K3T_THREADS, 0, s>>>(ix, mat, bfrag, nq, has_since, since_ms, tag_mask, T, n_sel, step,
+                                                                                seed, ws.bq_cand, ws.bq_total);
     };
     if (ev0) (void)hipEventRecord(ev0, s);
     const uint32_t* seed = nullptr;
@@ -2022,7 +2067,7 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* em
     const float margin = (bf16 ? LBH_MARGIN_BF16X3 : LBH_MARGIN) * norm_scale;
     e = hipMemsetAsync(ws.flags, 0, 16, s);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(ws.bq_total, 0, BQ_MAXQ * 4, s);
+    e = hipMemsetAsync(ws.bq_total, 0, BQ_MAXQ * BQ_QT * 4, s);
     if (e != hipSuccess) return e;
     const dim3 b(BQ_THREADS);
     auto launch = [&](int64_t r0, int64_t r1, const uint32_t* seed) {
