@@ -1194,7 +1194,10 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
         return t < n_tiles ? t : n_tiles - 1;
     };
     auto load_tile = [&](f32x4 (&a)[4], int64_t i) {  // always issued (index clamped): no load under a lane-dependent guard
-        const int64_t t = tile_of(i < n_sel ? i : n_sel - 1);
+        int64_t t = tile_of(i < n_sel ? i : n_sel - 1);
+#ifdef K3T_L2WINDOW  // timing-only build: every tile comes from a 1 MiB, cache-resident window (what the scan costs without HBM)
+        t &= 255;
+#endif
         const f32x4* p = emb16t + t * 256 + lane;
 #pragma unroll
         for (int s = 0; s < 4; ++s) a[s] = __builtin_nontemporal_load(p + s * 64);
@@ -1210,6 +1213,8 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
         for (int s = 0; s < 4; ++s)
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, araw[s]), __builtin_bit_cast(f16x8, braw[s]), acc, 0, 0, 0);
         const float thr = ldsthr[g * 32 + j];
+        // (v_max3_f32 through inline asm would save the two quieting v_max(x, x) the compiler adds, but the hazard
+        // recogniser does not see an asm operand as a reader of MFMA results: it dropped the wait states and rows were missed)
         const float m0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
         const float m1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
         const float m2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]);
@@ -1217,7 +1222,8 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
         const float m4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
         const float m5 = __builtin_fmaxf(__builtin_fmaxf(m0, m1), m2);
         const float m6 = __builtin_fmaxf(__builtin_fmaxf(m3, m4), acc[15]);
-        const bool lanehit = __builtin_fmaxf(m5, m6) >= thr;
+        const float mx = __builtin_fmaxf(m5, m6);
+        const bool lanehit = mx >= thr;
         if (__any(lanehit))  // rare: some query of this group has a row at or above its threshold
             cnt = k3t_harvest(acc, thr, lanehit, 32 * g + j, row0, n, ix.created, ix.tags, has_since, since_ms, tag_mask, se, sq,
                               cnt, cand3, qtotal);
@@ -1312,6 +1318,7 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_batched_kernel(int k, float 
     __shared__ int hist[256];
     __shared__ int64_t sh_krem;
     __shared__ int sh_bin;
+    __shared__ uint32_t sord[BQ_PERQ];  // the list's scores (ordered images), staged once: the select's five passes read LDS
     const int q = blockIdx.x;
     const int raw = qtotal[q * BQ_QT];
     int E = dense > 0 ? dense : (raw & (BQ_OVER - 1));
@@ -1319,8 +1326,10 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_batched_kernel(int k, float 
     const uint64_t* cand = cand3 + (size_t)q * BQ_PERQ;
     uint32_t thr = 0;
     if (E >= k) {
+        for (int e = threadIdx.x; e < E; e += SEL_THREADS) sord[e] = (uint32_t)(cand[e] >> 32);
+        __syncthreads();
         auto val = [&](int e, uint64_t* v) {
-            *v = cand[e] >> 32;
+            *v = sord[e];
             return true;
         };
         const uint32_t kth = (uint32_t)block_radix_select(E, 4, k, val, hist, &sh_krem, &sh_bin);
