@@ -192,13 +192,13 @@ def main():
     have_gpu = torch.cuda.is_available()  # False only in the CPU rehearsal of the launcher (tests/bench_cpu_harness.py)
     if have_gpu or not rehearse:
         torch.cuda.set_device(local_rank)
-    coll_dev = "cpu" if rehearse else "cuda"
+    coll_dev = "cpu"
     if world > 1:
+        # torch.distributed is plumbing only (rendezvous, barriers, the max / sum of the timing scalars), over gloo on the
+        # host; the data path's one collective -- the all-gather of the per-GPU top-k lists -- runs inside liblbhip on RCCL
+        # (lbh_index_search_sharded).  The rehearsal has no second GPU, so there the lists travel over gloo as well.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")
 
     from lbm_amd import _hip, synth
     from lbm_amd.sharded import ShardedSearcher
@@ -230,7 +230,13 @@ def main():
 
     queries = synth.make_queries(args.queries, seed=4321)
     qvecs = _hip.embed_batch(queries)
-    searcher = ShardedSearcher(ix.search_shard, rank, world, device=None if rehearse else torch.device("cuda", local_rank))
+    searcher = comm = None
+    if world > 1 and rehearse:
+        searcher = ShardedSearcher(ix.search_shard, rank, world, device=None)
+    elif world > 1:
+        uid = [_hip.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = _hip.Comm(uid[0], rank, world)  # collective: RCCL communicator over the node's xGMI links
     stats = _hip.Stats()
     every = max(1, args.time_every)
 
@@ -241,6 +247,8 @@ def main():
             # record costs ~3 us of queue time, so the other launches run without them)
             stats.want_timing = 1 if i % every == 0 else 0
             return ix.search_shard(q, args.top_k, since, 0, stats)
+        if comm is not None:
+            return ix.search_sharded(comm, q, args.top_k, since, 0)
         return searcher.search(q, args.top_k, since, 0)
 
     def fence():
@@ -310,7 +318,9 @@ def main():
             "config": {"workload": f"{args.claims}-claim shard per GPU (synthetic Zipf corpus, 1% retracted), "
                                    f"single-query compile_context ranking, top_k={args.top_k}, since_ms={args.since}",
                        "claims_per_gpu": args.claims, "live_claims_total": total_live, "top_k": args.top_k,
-                       "parallelism": f"claim-sharded x{world}, all-gather top-k merge" if world > 1 else "single GPU"},
+                       "parallelism": (f"claim-sharded x{world}, one RCCL all-gather of the per-GPU top-k lists per query (inside liblbhip), "
+                                       "same-comparator merge" if comm is not None else f"claim-sharded x{world}, lists gathered over gloo (rehearsal)")
+                       if world > 1 else "single GPU"},
             "latency_ms": {"p50": float(np.percentile(lat, 50) * 1e3), "p99": float(np.percentile(lat, 99) * 1e3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -351,6 +361,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

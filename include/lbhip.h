@@ -40,6 +40,8 @@ extern "C" {
 
 typedef struct lbh_ctx lbh_ctx;
 typedef struct lbh_index lbh_index;
+typedef struct lbh_comm lbh_comm;   /* one rank's end of the claim-sharded search's exchange (RCCL communicator + buffers) */
+#define LBH_COMM_ID_BYTES 128       /* size of the rendezvous id (an RCCL unique id) */
 
 /* Per-search statistics (all optional; pass NULL to skip).  Times are HIP-event
  * times on the library's own stream. */
@@ -178,6 +180,28 @@ int lbh_search_dev_noalloc(lbh_ctx* ctx, const float* emb32_dev, const double* e
                            const uint64_t* tagmask_dev, const uint64_t* keywords_dev, int64_t n, double max_row_norm,
                            const double* q_f64, int64_t k, int64_t since_ms, uint64_t tag_mask, int64_t* out_rows_dev,
                            double* out_scores_dev, int64_t* out_count_dev);
+
+/* ---- claim-sharded search over the GPUs of a node: one process per GPU, one index (shard) per process.  The reference
+ * ranks by a total order on (-score, claim_hash) with unique hashes (lb/context_graph.py:120) and a claim's score depends
+ * on that claim and the query alone, so the global top-k is inside the union of the shards' top-k lists.
+ *
+ * lbh_comm_unique_id   rank 0 draws the rendezvous id and hands it to the other ranks by any channel it likes (a file,
+ *                      MPI, torch.distributed); needs librccl (opened on first use), no GPU work.
+ * lbh_comm_init        every rank: joins the communicator (collective: returns when all `world` ranks have called it).
+ * lbh_index_search_sharded   every rank, same query / k / filters (collective): exact local top-k on this rank's shard
+ *                      (the kernels of lbh_index_search_shard), ONE all-gather of the ranks' lists -- (k + 1) x 48 bytes per
+ *                      rank, read from the device memory the final kernel wrote them to, RCCL over xGMI on the library's
+ *                      stream -- and the merge with the reference's comparator (lbh_merge_topk).  Every rank returns the
+ *                      same global result: out_gids[i] = local claim id * gid_mul + gid_add of the owning rank (e.g.
+ *                      gid_mul = world, gid_add = rank for claims dealt round-robin), fp64 scores bit-identical to the
+ *                      reference's, the 32-byte hash keys (out_keys may be NULL).  top_k <= LBH_MAX_PAGE takes one host
+ *                      wait per query; larger k is paged locally first and exchanged through staging buffers. */
+int lbh_comm_unique_id(uint8_t* out_id /* LBH_COMM_ID_BYTES */);
+int lbh_comm_init(lbh_ctx* ctx, const uint8_t* id, int rank, int world, lbh_comm** out_comm);
+int lbh_comm_destroy(lbh_comm* comm);
+int lbh_index_search_sharded(lbh_index* idx, lbh_comm* comm, const double* q_f64, int64_t k, int64_t since_ms,
+                             uint64_t tag_mask, uint64_t gid_mul, uint64_t gid_add, uint64_t* out_gids, double* out_scores,
+                             uint8_t* out_keys, int64_t* out_count, lbh_stats* stats);
 
 /* Merge step of the claim-sharded search (host code, needs no GPU): `lists` = n_lists blocks of (k + 1) x 6
  * int64, as exchanged by the all-gather -- row 0 word 0 = entry count (<= k), rows 1.. = {fp64 score bits,

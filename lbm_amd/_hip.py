@@ -34,6 +34,7 @@ EXPORTS = [
     "lbh_index_get_embeddings",
     "lbh_index_search", "lbh_index_search_text", "lbh_index_search_shard",
     "lbh_index_recent", "lbh_index_set_order", "lbh_merge_topk", "lbh_search_dev_noalloc",
+    "lbh_comm_unique_id", "lbh_comm_init", "lbh_comm_destroy", "lbh_index_search_sharded",
 ]
 
 
@@ -136,6 +137,11 @@ def load_library() -> ctypes.CDLL:
                                              ctypes.POINTER(Stats)]
         L.lbh_search_dev_noalloc.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, _vp, _i64, _i64, _u64,
                                              _vp, _vp, _vp]
+        L.lbh_comm_unique_id.argtypes = [_vp]
+        L.lbh_comm_init.argtypes = [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]
+        L.lbh_comm_destroy.argtypes = [_vp]
+        L.lbh_index_search_sharded.argtypes = [_vp, _vp, _vp, _i64, _i64, _u64, _u64, _u64, _vp, _vp, _vp, ctypes.POINTER(_i64),
+                                               ctypes.POINTER(Stats)]
         for name in EXPORTS:
             if name not in ("lbh_last_error", "lbh_version"):
                 getattr(L, name).restype = ctypes.c_int
@@ -253,6 +259,41 @@ def cosine(a: np.ndarray, b: np.ndarray) -> float:
     out = ctypes.c_double(0.0)
     _check(load_library().lbh_cosine(context(), _ptr(a), a.shape[0], _ptr(b), b.shape[0], ctypes.byref(out)))
     return out.value
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """Rendezvous id of a claim-sharded search group (rank 0 draws it and hands it to the other ranks)."""
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    _check(load_library().lbh_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """One rank's end of the sharded search's exchange (``lbh_comm*``: an RCCL communicator on this process's GPU).
+    Creating it is collective: it returns once all ``world`` ranks have called it with the same id."""
+
+    def __init__(self, uid: bytes, rank: int, world: int) -> None:
+        if len(uid) != COMM_ID_BYTES:
+            raise ValueError("uid must be the %d bytes comm_unique_id() returned" % COMM_ID_BYTES)
+        self._L = load_library()
+        self.rank, self.world = int(rank), int(world)
+        h = _vp()
+        _check(self._L.lbh_comm_init(context(), ctypes.c_char_p(uid), self.rank, self.world, ctypes.byref(h)))
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.lbh_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Index:
@@ -393,6 +434,30 @@ class Index:
                                              ctypes.byref(stats) if stats is not None else None))
         n = cnt.value
         return ids[:n], sc[:n], qv
+
+    def search_sharded(self, comm: "Comm", q: np.ndarray, k: int, since_ms: int = SINCE_NONE, tag_mask: int = 0,
+                       stats: Optional[Stats] = None, gid_mul: Optional[int] = None, gid_add: Optional[int] = None):
+        """Collective over ``comm``: global top-k of the claim-sharded corpus -> (global ids, scores, keys[n, 32]),
+        identical on every rank.  Global id = local id * gid_mul + gid_add (default: world, rank = round-robin deal)."""
+        if not (isinstance(q, np.ndarray) and q.dtype == np.float64 and q.shape == (DIM,) and q.flags.c_contiguous):
+            q = np.ascontiguousarray(q, dtype=np.float64).reshape(DIM)
+        k = max(0, int(k))
+        mul = comm.world if gid_mul is None else int(gid_mul)
+        add = comm.rank if gid_add is None else int(gid_add)
+        with self._shard_lock:
+            buf = self._shard_bufs.get(("x", k))
+            if buf is None:
+                kk = max(k, 1)
+                ids = np.zeros(kk, dtype=np.uint64)
+                sc = np.zeros(kk, dtype=np.float64)
+                keys = np.zeros((kk, KEY_BYTES), dtype=np.uint8)
+                cnt = _i64(0)
+                buf = self._shard_bufs[("x", k)] = (ids, sc, keys, cnt, _ptr(ids), _ptr(sc), _ptr(keys), ctypes.byref(cnt))
+            ids, sc, keys, cnt, p_ids, p_sc, p_keys, p_cnt = buf
+            _check(self._L.lbh_index_search_sharded(self._h, comm._h, q.ctypes.data, k, _since(since_ms), int(tag_mask), mul, add,
+                                                    p_ids, p_sc, p_keys, p_cnt, ctypes.byref(stats) if stats is not None else None))
+            n = cnt.value
+            return ids[:n].copy(), sc[:n].copy(), keys[:n].copy()
 
     def search_shard(self, q: np.ndarray, k: int, since_ms: int = SINCE_NONE, tag_mask: int = 0,
                      stats: Optional[Stats] = None):

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <dlfcn.h>
 #include <mutex>
 #include <new>
 #include <string>
@@ -72,6 +73,7 @@ struct lbh_index {
     uint64_t* tags = nullptr;
     uint64_t* keys = nullptr;
     uint64_t* order = nullptr;    // per-row insertion-order key of the recency query (defaults to the claim id)
+    uint64_t* ids = nullptr;      // per-row claim id (device mirror of id_of_row: the sharded search emits global ids on the GPU)
     uint16_t* emb16 = nullptr;    // n x 64 fp16 (128 B rows), built on first use of scan_mode 1; rows [0, emb16_rows) are valid
     int64_t emb16_rows = 0, emb16_cap = 0;
     std::vector<uint64_t> id_of_row;
@@ -140,6 +142,7 @@ int index_reserve_locked(lbh_index* ix, int64_t want) {
     if ((rc = grow_array(ix->tags, ix->n, want, 1, s))) return rc;
     if ((rc = grow_array(ix->keys, ix->n, want, 4, s))) return rc;
     if ((rc = grow_array(ix->order, ix->n, want, 1, s))) return rc;
+    if ((rc = grow_array(ix->ids, ix->n, want, 1, s))) return rc;
     if (ix->emb16) {  // rebuilt lazily at the next fp16 scan
         (void)hipFree(ix->emb16);
         ix->emb16 = nullptr;
@@ -177,6 +180,7 @@ lbh_dev_index dev_view(const lbh_index* ix) {
     d.created = ix->created;
     d.tags = ix->tags;
     d.keys = ix->keys;
+    d.ids = ix->ids;
     d.n = ix->n;
     return d;
 }
@@ -584,7 +588,7 @@ int lbh_index_destroy(lbh_index* ix) {
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
     lbh_workspace& w = ix->ws;
-    void* dev[] = {ix->emb16, ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, ix->order, w.rc_a, w.rc_b, w.rc_row, w.rc_cnt, w.q64, w.cand, w.xcand_ord, w.xcand_row,
+    void* dev[] = {ix->emb16, ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, ix->order, ix->ids, w.rc_a, w.rc_b, w.rc_row, w.rc_cnt, w.q64, w.cand, w.xcand_ord, w.xcand_row,
                    w.flags, w.bq_qmat, w.bq_cand, w.bq_total, w.bq_seed, w.bq_bfrag};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -635,6 +639,7 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
     HIP_TRY(hipMemcpyAsync(ix->tags + r0, h_tags, (size_t)n * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(ix->keys + r0 * 4, h_keys, (size_t)n * 32, hipMemcpyHostToDevice, s));
     HIP_TRY(lbh_launch_iota_u64(ix->order + r0, (uint64_t)ix->row_of_id.size(), n, s));
+    HIP_TRY(lbh_launch_iota_u64(ix->ids + r0, (uint64_t)ix->row_of_id.size(), n, s));
     double batch_norm = 1.0;  // K1 writes unit vectors (or zero)
     if (emb_f64) {
         batch_norm = 0.0;
@@ -685,7 +690,7 @@ int lbh_index_retract(lbh_index* ix, uint64_t id) {
     HIP_TRY(hipSetDevice(ix->ctx->device));
     const int64_t r = ix->row_of_id[(size_t)id], last = ix->n - 1;
     if (r != last) {
-        HIP_TRY(lbh_launch_move_row(ix->emb32, ix->emb64, (ix->emb16 && ix->emb16_rows == ix->n) ? ix->emb16 : nullptr, ix->created, ix->tags, ix->keys, ix->order, r, last, ix->ctx->stream));
+        HIP_TRY(lbh_launch_move_row(ix->emb32, ix->emb64, (ix->emb16 && ix->emb16_rows == ix->n) ? ix->emb16 : nullptr, ix->created, ix->tags, ix->keys, ix->order, ix->ids, r, last, ix->ctx->stream));
         const uint64_t moved = ix->id_of_row[(size_t)last];
         ix->id_of_row[(size_t)r] = moved;
         ix->row_of_id[(size_t)moved] = r;
@@ -741,7 +746,7 @@ int lbh_index_retract_many(lbh_index* ix, int64_t n, const uint64_t* ids) {
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(ix->dscratch, pairs, (size_t)n_holes * 16, hipMemcpyHostToDevice, s));
         HIP_TRY(lbh_launch_move_rows(ix->emb32, ix->emb64, (ix->emb16 && ix->emb16_rows == ix->n) ? ix->emb16 : nullptr, ix->created,
-                                     ix->tags, ix->keys, ix->order, reinterpret_cast<const int64_t*>(ix->dscratch), n_holes, s));
+                                     ix->tags, ix->keys, ix->order, ix->ids, reinterpret_cast<const int64_t*>(ix->dscratch), n_holes, s));
         HIP_TRY(hipStreamSynchronize(s));  // the staging area is reused by the next call
     }
     for (int64_t i = 0; i < n; ++i) ix->row_of_id[(size_t)ids[i]] = -1;
@@ -1112,7 +1117,7 @@ int lbh_search_dev_noalloc(lbh_ctx* c, const float* emb32_dev, const double* emb
     std::lock_guard<std::mutex> lk(c->noalloc_mu);
     HIP_TRY(hipSetDevice(c->device));
     lbh_dev_index dv;
-    dv.emb32 = emb32_dev; dv.emb64 = emb64_dev; dv.created = created_ms_dev; dv.tags = tagmask_dev; dv.keys = keywords_dev; dv.n = n;
+    dv.emb32 = emb32_dev; dv.emb64 = emb64_dev; dv.created = created_ms_dev; dv.tags = tagmask_dev; dv.keys = keywords_dev; dv.ids = nullptr; dv.n = n;
     if (n == 0 || k == 0) {  // nothing to scan: only the count is written (stream-ordered, like everything else here)
         HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1137,6 +1142,267 @@ int lbh_index_search_shard(lbh_index* ix, const double* q_f64, int64_t k, int64_
     int rc = load_query(ix, q_f64);
     if (rc) return rc;
     return search_loaded(ix, k, since_ms, tag_mask, out_ids, out_scores, out_keys, out_count, stats);
+}
+
+}  // extern "C"
+
+// ---- claim-sharded search: the exchange step behind the C ABI (RCCL all-gather over xGMI) ---------------------
+// librccl is opened on first use (dlopen), so a single-GPU deployment needs no RCCL at all.
+namespace {
+struct RcclId128 { char b[128]; };  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId128, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+std::once_flag g_rccl_once;
+std::string g_rccl_err;
+
+int rccl_api() {
+    std::call_once(g_rccl_once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* nm : names) {
+            g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+            if (g_rccl.lib) break;
+        }
+        if (!g_rccl.lib) { g_rccl_err = std::string("cannot open librccl: ") + dlerror(); return; }
+        g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(g_rccl.lib, "ncclGetUniqueId"));
+        g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(g_rccl.lib, "ncclCommInitRank"));
+        g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(g_rccl.lib, "ncclCommDestroy"));
+        g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(g_rccl.lib, "ncclAllGather"));
+        g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(g_rccl.lib, "ncclGetErrorString"));
+        if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetErrorString)
+            g_rccl_err = "librccl lacks an expected symbol";
+    });
+    if (!g_rccl_err.empty()) return fail(LBH_E_DEVICE, "%s", g_rccl_err.c_str());
+    return LBH_OK;
+}
+#define RCCL_TRY(expr)                                                                                  \
+    do {                                                                                                \
+        const int r__ = (expr);                                                                         \
+        if (r__ != 0) return fail(LBH_E_DEVICE, "%s: %s", #expr, g_rccl.GetErrorString(r__));          \
+    } while (0)
+constexpr int NCCL_INT8 = 0;  // ncclInt8 / ncclChar
+}  // namespace
+
+struct lbh_comm {
+    lbh_ctx* ctx = nullptr;
+    void* comm = nullptr;
+    int rank = 0, world = 1;
+    std::mutex mu;
+    int64_t* send_dev = nullptr;       // LBH_XCHG_WORDS: this rank's packed list, written by the select kernel
+    int64_t* recv_dev = nullptr;       // world x LBH_XCHG_WORDS
+    int64_t* recv_host = nullptr;      // the same, device-mapped pinned host memory, + one ticket word behind it
+    int64_t* recv_host_dev = nullptr;
+    int32_t seq = 0;
+    // top_k > LBH_MAX_PAGE: lists of (k + 1) x 6 words staged through the host (rare)
+    int64_t* big_send_host = nullptr;  // pinned
+    int64_t* big_recv_host = nullptr;  // pinned
+    int64_t* big_send_dev = nullptr;
+    int64_t* big_recv_dev = nullptr;
+    int64_t big_k = 0;
+};
+
+extern "C" {
+
+int lbh_comm_unique_id(uint8_t* out_id) {
+    if (!out_id) return fail(LBH_E_INVALID, "bad argument");
+    int rc = rccl_api();
+    if (rc) return rc;
+    RCCL_TRY(g_rccl.GetUniqueId(out_id));
+    return LBH_OK;
+}
+
+int lbh_comm_destroy(lbh_comm* cm) {
+    if (!cm) return LBH_OK;
+    (void)hipSetDevice(cm->ctx->device);
+    (void)hipStreamSynchronize(cm->ctx->stream);
+    if (cm->comm) (void)g_rccl.CommDestroy(cm->comm);
+    void* dev[] = {cm->send_dev, cm->recv_dev, cm->big_send_dev, cm->big_recv_dev};
+    for (void* p : dev)
+        if (p) (void)hipFree(p);
+    void* host[] = {cm->recv_host, cm->big_send_host, cm->big_recv_host};
+    for (void* p : host)
+        if (p) (void)hipHostFree(p);
+    delete cm;
+    return LBH_OK;
+}
+
+int lbh_comm_init(lbh_ctx* c, const uint8_t* id, int rank, int world, lbh_comm** out_comm) {
+    if (!c || !id || !out_comm || world < 1 || rank < 0 || rank >= world) return fail(LBH_E_INVALID, "bad argument");
+    *out_comm = nullptr;
+    int rc = rccl_api();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    lbh_comm* cm = new (std::nothrow) lbh_comm();
+    if (!cm) return fail(LBH_E_NOMEM, "out of host memory");
+    cm->ctx = c;
+    cm->rank = rank;
+    cm->world = world;
+    auto bail = [&](int code) {
+        const std::string why = g_err;
+        lbh_comm_destroy(cm);
+        g_err = why;
+        return code;
+    };
+    RcclId128 uid;
+    memcpy(uid.b, id, sizeof uid.b);
+    {
+        const int r = g_rccl.CommInitRank(&cm->comm, world, uid, rank);
+        if (r != 0) return bail(fail(LBH_E_DEVICE, "ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString(r)));
+    }
+    const size_t words = (size_t)LBH_XCHG_WORDS;
+    hipError_t e = hipMalloc((void**)&cm->send_dev, words * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&cm->recv_dev, words * 8 * (size_t)world);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&cm->recv_host, words * 8 * (size_t)world + 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&cm->recv_host_dev, cm->recv_host, 0);
+    if (e == hipSuccess) e = hipMemset(cm->send_dev, 0, words * 8);
+    if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? LBH_E_NOMEM : LBH_E_DEVICE, "exchange buffers: %s", hipGetErrorString(e)));
+    memset(cm->recv_host, 0, words * 8 * (size_t)world + 64);
+    *out_comm = cm;
+    return LBH_OK;
+}
+
+int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, int64_t k, int64_t since_ms, uint64_t tag_mask,
+                             uint64_t gid_mul, uint64_t gid_add, uint64_t* out_gids, double* out_scores, uint8_t* out_keys,
+                             int64_t* out_count, lbh_stats* stats) {
+    if (!ix || !cm || !q_f64 || !out_count) return fail(LBH_E_INVALID, "bad argument");
+    if (cm->ctx != ix->ctx) return fail(LBH_E_INVALID, "the communicator and the index belong to different contexts");
+    if (k < 0) k = 0;
+    if (k > 0 && (!out_gids || !out_scores)) return fail(LBH_E_INVALID, "output arrays are NULL");
+    *out_count = 0;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    std::lock_guard<std::mutex> lk2(cm->mu);
+    lbh_ctx* c = ix->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    int rc = load_query(ix, q_f64);
+    if (rc) return rc;
+    if (stats) {
+        const int32_t wt = stats->want_timing;
+        memset(stats, 0, sizeof *stats);
+        stats->want_timing = wt;
+    }
+    if (k == 0) return LBH_OK;  // every rank returns here: no collective for an empty request
+    const bool timing = stats && stats->want_timing;
+    const int W = cm->world;
+    std::vector<int64_t> merged;
+    int64_t kk = k;  // entries per list
+    const int64_t* lists = nullptr;
+    if (k <= LBH_MAX_PAGE) {
+        // Stream-ordered, one host wait: fp32 scan -> select (writes the packed list to cm->send_dev) -> exact fp64 scan
+        // and select, which return at once unless the fast path reported an unbounded candidate set -> all-gather of the
+        // device-resident lists over xGMI -> copy into mapped host memory + ticket.
+        const lbh_dev_index dv = dev_view(ix);
+        const int has_since = since_ms != LBH_SINCE_NONE;
+        const int page = (int)k;
+        const lbh_xchg xc{cm->send_dev, gid_mul, gid_add};
+        const float nscale = norm_scale(ix, ix->qnorm);
+        const int32_t seq = ix->seq = (ix->seq == INT32_MAX) ? 1 : ix->seq + 1;
+        HIP_TRY(hipMemsetAsync(cm->send_dev, 0, 48, s));  // count 0 if this shard is empty / nothing passes
+        if (ix->n > 0) {
+            const int grid = lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu);
+            const bool half = c->scan_mode == 1 && nscale <= 1.001f && nscale >= 0.25f;
+            if (half) {
+                rc = ensure_emb16(ix);
+                if (rc) return rc;
+            }
+            HIP_TRY(lbh_launch_search_fast(dv, half ? ix->emb16 : nullptr, ix->ws, nullptr, ix->qarg, page, has_since, since_ms, tag_mask, grid,
+                                           c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, timing ? ix->ev[0] : nullptr,
+                                           timing ? ix->ev[1] : nullptr, &xc));
+            lbh_cursor cur;
+            memset(&cur, 0, sizeof cur);
+            HIP_TRY(lbh_launch_search_exact(dv, ix->ws, nullptr, ix->qarg, page, has_since, since_ms, tag_mask, cur, std::min(grid, 512), seq, s,
+                                            nullptr, nullptr, &xc, &ix->ws.result_dev->overflow));
+            if (stats) {
+                stats->rows_scanned = ix->n;
+                stats->bytes_per_row = (half ? 128 : 256) + (has_since ? 8 : 0) + (tag_mask ? 8 : 0);
+                stats->scan_launches = 1;
+            }
+        }
+        RCCL_TRY(g_rccl.AllGather(cm->send_dev, cm->recv_dev, (size_t)LBH_XCHG_WORDS * 8, NCCL_INT8, cm->comm, s));
+        const int32_t xseq = cm->seq = (cm->seq == INT32_MAX) ? 1 : cm->seq + 1;
+        int32_t* ticket_host = reinterpret_cast<int32_t*>(cm->recv_host + (size_t)LBH_XCHG_WORDS * W);
+        int32_t* ticket_dev = reinterpret_cast<int32_t*>(cm->recv_host_dev + (size_t)LBH_XCHG_WORDS * W);
+        HIP_TRY(lbh_launch_xchg_publish(cm->recv_dev, cm->recv_host_dev, LBH_XCHG_WORDS * W, ticket_dev, xseq, s));
+        HIP_TRY(wait_ticket(c, ticket_host, xseq));
+        if (timing && ix->n > 0) {
+            HIP_TRY(hipEventSynchronize(ix->ev[1]));
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]) == hipSuccess) stats->scan_ms = ms;
+        }
+        if (stats && ix->n > 0) {
+            const lbh_result* r = ix->ws.result_host;
+            stats->candidates = r->candidates;
+        }
+        // lists are LBH_MAX_PAGE + 1 rows apart; lbh_merge_topk wants (kk + 1) rows: compact in place on the host copy
+        merged.resize((size_t)W * (size_t)(k + 1) * 6);
+        for (int r = 0; r < W; ++r) {
+            const int64_t* src = cm->recv_host + (size_t)r * LBH_XCHG_WORDS;
+            if (src[0] < 0) return fail(LBH_E_INTERNAL, "rank %d: more than %d claims tie on score AND carry the same 32-byte hash key", r, LBH_MCAP);
+            memcpy(merged.data() + (size_t)r * (size_t)(k + 1) * 6, src, (size_t)(k + 1) * 48);
+        }
+        lists = merged.data();
+    } else {
+        // top_k beyond one device page: the local pages are collected on the host (fast page + exact pages), then exchanged
+        // through staging buffers.  Rare, and dominated by the paged scans anyway.
+        const int64_t kl = std::min<int64_t>(k, std::max<int64_t>(ix->n, 1));
+        (void)kl;
+        if (cm->big_k < k) {
+            void* dev[] = {cm->big_send_dev, cm->big_recv_dev};
+            for (void* p : dev)
+                if (p) (void)hipFree(p);
+            void* host[] = {cm->big_send_host, cm->big_recv_host};
+            for (void* p : host)
+                if (p) (void)hipHostFree(p);
+            cm->big_send_dev = cm->big_recv_dev = cm->big_send_host = cm->big_recv_host = nullptr;
+            cm->big_k = 0;
+            const size_t bytes = (size_t)(k + 1) * 48;
+            HIP_TRY(hipMalloc((void**)&cm->big_send_dev, bytes));
+            HIP_TRY(hipMalloc((void**)&cm->big_recv_dev, bytes * (size_t)W));
+            HIP_TRY(hipHostMalloc((void**)&cm->big_send_host, bytes, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc((void**)&cm->big_recv_host, bytes * (size_t)W, hipHostMallocDefault));
+            cm->big_k = k;
+        }
+        std::vector<uint64_t> ids((size_t)k);
+        std::vector<double> sc((size_t)k);
+        std::vector<uint8_t> keys((size_t)k * 32);
+        int64_t got = 0;
+        rc = search_loaded(ix, k, since_ms, tag_mask, ids.data(), sc.data(), keys.data(), &got, stats);
+        if (rc) return rc;
+        int64_t* sh = cm->big_send_host;
+        memset(sh, 0, (size_t)(k + 1) * 48);
+        sh[0] = got;
+        for (int64_t i = 0; i < got; ++i) {
+            int64_t* e = sh + 6 * (i + 1);
+            memcpy(&e[0], &sc[(size_t)i], 8);
+            e[1] = (int64_t)(ids[(size_t)i] * gid_mul + gid_add);
+            for (int w = 0; w < 4; ++w) e[2 + w] = (int64_t)load_be64(keys.data() + i * 32 + 8 * w);
+        }
+        const size_t bytes = (size_t)(k + 1) * 48;
+        HIP_TRY(hipMemcpyAsync(cm->big_send_dev, sh, bytes, hipMemcpyHostToDevice, s));
+        RCCL_TRY(g_rccl.AllGather(cm->big_send_dev, cm->big_recv_dev, bytes, NCCL_INT8, cm->comm, s));
+        HIP_TRY(hipMemcpyAsync(cm->big_recv_host, cm->big_recv_dev, bytes * (size_t)W, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        lists = cm->big_recv_host;
+    }
+    std::vector<int64_t> top((size_t)std::max<int64_t>(kk, 1) * 6);
+    int64_t cnt = 0;
+    rc = lbh_merge_topk(lists, W, kk, top.data(), &cnt);
+    if (rc) return rc;
+    for (int64_t i = 0; i < cnt; ++i) {
+        const int64_t* e = top.data() + i * 6;
+        memcpy(&out_scores[i], &e[0], 8);
+        out_gids[i] = (uint64_t)e[1];
+        if (out_keys)
+            for (int w = 0; w < 4; ++w) store_be64(out_keys + i * 32 + 8 * w, (uint64_t)e[2 + w]);
+    }
+    *out_count = cnt;
+    return LBH_OK;
 }
 
 }  // extern "C"

@@ -347,7 +347,7 @@ __global__ void f64_to_f16_tiled_kernel(const double* __restrict__ emb64, _Float
 
 // swap-delete support: copy row `src` over row `dst` in every per-claim array
 __global__ void move_row_kernel(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
-                                uint64_t* order, int64_t dst, int64_t src) {
+                                uint64_t* order, uint64_t* ids, int64_t dst, int64_t src) {
     const int l = threadIdx.x;
     emb32[dst * 64 + l] = emb32[src * 64 + l];
     if (emb16) emb16[lbh_emb16_off(dst, l)] = emb16[lbh_emb16_off(src, l)];
@@ -356,12 +356,13 @@ __global__ void move_row_kernel(float* emb32, double* emb64, uint16_t* emb16, in
     if (l == 4) created[dst] = created[src];
     if (l == 5) tags[dst] = tags[src];
     if (l == 6) order[dst] = order[src];
+    if (l == 7) ids[dst] = ids[src];
 }
 
 // batched swap-delete (lbh_index_retract_many): pair p copies row pairs[2p+1] (a survivor from the tail that is cut
 // off) over row pairs[2p] (a hole below the new end).  Sources and destinations are disjoint, so pairs are independent.
 __global__ void move_rows_kernel(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
-                                 uint64_t* order, const int64_t* __restrict__ pairs, int64_t n_pairs) {
+                                 uint64_t* order, uint64_t* ids, const int64_t* __restrict__ pairs, int64_t n_pairs) {
     const int l = threadIdx.x & 63;
     const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= n_pairs) return;
@@ -373,6 +374,7 @@ __global__ void move_rows_kernel(float* emb32, double* emb64, uint16_t* emb16, i
     if (l == 4) created[dst] = created[src];
     if (l == 5) tags[dst] = tags[src];
     if (l == 6) order[dst] = order[src];
+    if (l == 7) ids[dst] = ids[src];
 }
 
 // out[i] = emb64 row rows[i] (batched _embedding_cache reads)
@@ -420,15 +422,15 @@ hipError_t lbh_launch_f64_to_f32(const double* in_dev, float* out_dev, int64_t n
 }
 
 hipError_t lbh_launch_move_row(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
-                               uint64_t* order, int64_t dst, int64_t src, hipStream_t s) {
-    move_row_kernel<<<1, 64, 0, s>>>(emb32, emb64, emb16, created, tags, keys, order, dst, src);
+                               uint64_t* order, uint64_t* ids, int64_t dst, int64_t src, hipStream_t s) {
+    move_row_kernel<<<1, 64, 0, s>>>(emb32, emb64, emb16, created, tags, keys, order, ids, dst, src);
     return hipGetLastError();
 }
 
 hipError_t lbh_launch_move_rows(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
-                                uint64_t* order, const int64_t* pairs_dev, int64_t n_pairs, hipStream_t s) {
+                                uint64_t* order, uint64_t* ids, const int64_t* pairs_dev, int64_t n_pairs, hipStream_t s) {
     if (n_pairs <= 0) return hipSuccess;
-    move_rows_kernel<<<dim3((unsigned)((n_pairs + 3) / 4)), 256, 0, s>>>(emb32, emb64, emb16, created, tags, keys, order, pairs_dev, n_pairs);
+    move_rows_kernel<<<dim3((unsigned)((n_pairs + 3) / 4)), 256, 0, s>>>(emb32, emb64, emb16, created, tags, keys, order, ids, pairs_dev, n_pairs);
     return hipGetLastError();
 }
 

@@ -64,7 +64,16 @@ struct lbh_dev_index {
     const int64_t* created;   // n
     const uint64_t* tags;     // n
     const uint64_t* keys;     // n x 4, word 0 most significant (big-endian image of the 32 key bytes)
+    const uint64_t* ids;      // n: stable claim id of each row (NULL for caller-owned arrays: results then carry rows only)
     int64_t n;
+};
+
+// Optional second destination of a search's final kernel (claim-sharded search): the result as the packed list the ranks
+// exchange -- (LBH_MAX_PAGE + 1) x 6 int64 in DEVICE memory, row 0 = {count, ...}, then {fp64 score bits, global claim id
+// = id * gid_mul + gid_add, 4 key words} per result -- so that the all-gather reads it where it was produced.
+struct lbh_xchg {
+    int64_t* dst;             // NULL = not wanted
+    uint64_t gid_mul, gid_add;
 };
 
 // cursor for paging the exact path: only rows strictly AFTER (score, key) in the reference order pass
@@ -91,6 +100,7 @@ struct lbh_result {
     double scores[LBH_MAX_PAGE];
     uint64_t keys[LBH_MAX_PAGE][4];   // hash keys of the results (shard merge, paging cursor)
 };
+#define LBH_XCHG_WORDS ((LBH_MAX_PAGE + 1) * 6)  // int64 words of one rank's packed list
 
 // cursor for paging the recency query: only rows strictly AFTER (a, b) in (created desc, order asc) pass
 struct lbh_rcursor {
@@ -144,9 +154,9 @@ hipError_t lbh_launch_embed(const uint8_t* utf8_dev, const int64_t* offsets_dev,
 hipError_t lbh_launch_cosine(const double* a_dev, const double* b_dev, int64_t n, double* out_dev, hipStream_t s);
 hipError_t lbh_launch_f64_to_f32(const double* in_dev, float* out_dev, int64_t n_elems, hipStream_t s);
 hipError_t lbh_launch_move_row(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
-                               uint64_t* order, int64_t dst, int64_t src, hipStream_t s);
+                               uint64_t* order, uint64_t* ids, int64_t dst, int64_t src, hipStream_t s);
 hipError_t lbh_launch_move_rows(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
-                                uint64_t* order, const int64_t* pairs_dev, int64_t n_pairs, hipStream_t s);
+                                uint64_t* order, uint64_t* ids, const int64_t* pairs_dev, int64_t n_pairs, hipStream_t s);
 hipError_t lbh_launch_gather_rows_f64(const double* emb64, const int64_t* rows_dev, int64_t n, double* out_dev, hipStream_t s);
 hipError_t lbh_launch_f64_to_f16_tiled(const double* emb64_dev, uint16_t* emb16_dev, int64_t row0, int64_t row1, hipStream_t s);
 hipError_t lbh_launch_iota_u64(uint64_t* dst, uint64_t first, int64_t n, hipStream_t s);
@@ -157,11 +167,15 @@ int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu);
 hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, const double* qptr,
                                   const lbh_qarg& qa, int k, int has_since,
                                   int64_t since_ms, uint64_t tag_mask, int grid, int nt, int seq, float margin,
-                                  hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+                                  hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const lbh_xchg* xc = nullptr);
 hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
                                    const lbh_qarg& qa, int k, int has_since,
                                    int64_t since_ms, uint64_t tag_mask, const lbh_cursor& cur, int grid, int seq,
-                                   hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+                                   hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const lbh_xchg* xc = nullptr,
+                                   const int32_t* gate = nullptr);
+// copies the gathered lists (n_words int64) from device memory into device-mapped host memory and publishes `seq`
+hipError_t lbh_launch_xchg_publish(const int64_t* recv_dev, int64_t* recv_host_dev, int n_words, int32_t* ticket_host_dev, int seq,
+                                   hipStream_t s);
 hipError_t lbh_launch_recent(const int64_t* created, const uint64_t* order, int64_t n, const lbh_workspace& ws,
                              int page, int has_since, int64_t since_ms, const lbh_rcursor& cur, int64_t anchor_row,
                              int n_cu, int seq, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);

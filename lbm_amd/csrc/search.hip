@@ -402,7 +402,7 @@ __device__ uint64_t block_radix_select(int E, int nbytes, int64_t krem, F val, i
 // shared tail of both final kernels: rows xr[0..M) (+ ord64 scores xo when have_scores) -> exact
 // scores -> exact sort -> result block
 __device__ void rerank_and_emit(uint64_t* xo, uint32_t* xr, int M, int k, const lbh_dev_index& ix,
-                                const double* qs, lbh_result* __restrict__ res, bool have_scores,
+                                const double* qs, lbh_result* __restrict__ res, bool have_scores, const lbh_xchg& xc,
                                 uint32_t scan_ord0 = 0, uint32_t scan_ord1 = 0) {
     const int tid = threadIdx.x;
     const int n2 = pow2_at_least(M, 2);
@@ -432,14 +432,24 @@ __device__ void rerank_and_emit(uint64_t* xo, uint32_t* xr, int M, int k, const 
         res->scores[tid] = lbh_unord64(xo[tid]);
 #pragma unroll
         for (int w = 0; w < 4; ++w) res->keys[tid][w] = ix.keys[(size_t)r * 4 + w];
+        if (xc.dst) {  // the same result as the packed list the ranks exchange, left in device memory
+            int64_t* e = xc.dst + 6 * (tid + 1);
+            e[0] = (int64_t)__builtin_bit_cast(uint64_t, lbh_unord64(xo[tid]));
+            e[1] = (int64_t)((ix.ids ? ix.ids[r] : (uint64_t)r) * xc.gid_mul + xc.gid_add);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) e[2 + w] = (int64_t)ix.keys[(size_t)r * 4 + w];
+        }
     }
-    if (tid == 0) { res->count = cnt; res->overflow = 0; res->candidates = M; res->max_err = __builtin_bit_cast(float, sh_err); }
+    if (tid == 0) {
+        res->count = cnt; res->overflow = 0; res->candidates = M; res->max_err = __builtin_bit_cast(float, sh_err);
+        if (xc.dst) xc.dst[0] = cnt;
+    }
 }
 
 // K4 body: global fp32 threshold over E flat candidates, candidate cut, exact fp64 re-rank.
 // `qs` (64 doubles in LDS) must be filled and a barrier passed before the call.
 __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int k, const uint64_t* __restrict__ cand,
-                                 int E, lbh_result* __restrict__ res, float margin) {
+                                 int E, lbh_result* __restrict__ res, float margin, const lbh_xchg& xc = lbh_xchg{nullptr, 0, 0}) {
     __shared__ uint64_t sbuf[2 * LBH_MCAP];      // 32 KB: entries, later (ord64 | rows)
     __shared__ int hist[256];
     __shared__ int64_t sh_krem;
@@ -524,7 +534,7 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
     if (tid < M) xr[tid] = myrows[0];
     if (tid + SEL_THREADS < M) xr[tid + SEL_THREADS] = myrows[1];
     __syncthreads();
-    rerank_and_emit(xo, xr, M, k, ix, qs, res, false, myord[0], myord[1]);
+    rerank_and_emit(xo, xr, M, k, ix, qs, res, false, xc, myord[0], myord[1]);
 }
 
 // Completion ticket: the result block lives in device-mapped pinned host memory, so once every writer
@@ -541,7 +551,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index 
                                                                    lbh_qarg qa, int k,
                                                                    const uint64_t* __restrict__ cand,
                                                                    int32_t* __restrict__ flags,
-                                                                   lbh_result* __restrict__ res, int seq, float margin) {
+                                                                   lbh_result* __restrict__ res, int seq, float margin, lbh_xchg xc) {
     __shared__ double qs[64];
     const int tid = threadIdx.x;
     const int overflowed = flags[0];
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index 
     if (overflowed) {
         if (tid == 0) { res->count = 0; res->overflow = 1; res->candidates = 0; }
     } else {
-        select_fast_body(ix, qs, k, cand, E, res, margin);
+        select_fast_body(ix, qs, k, cand, E, res, margin, xc);
     }
     publish_result(res, seq);
 }
@@ -1452,7 +1462,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_exact_kernel(lbh_dev_index
                                                                     const uint32_t* __restrict__ xc_row,
                                                                     int32_t* __restrict__ flags,
                                                                     lbh_result* __restrict__ res, int seq,
-                                                                    const int32_t* __restrict__ gate) {
+                                                                    const int32_t* __restrict__ gate, lbh_xchg xc) {
     __shared__ uint64_t sbuf[2 * LBH_MCAP];
     __shared__ int hist[256];
     __shared__ int64_t sh_krem;
@@ -1534,9 +1544,12 @@ __global__ __launch_bounds__(SEL_THREADS) void select_exact_kernel(lbh_dev_index
     __syncthreads();
     const int M = sh_cnt;
     if (M > LBH_MCAP) {
-        if (tid == 0) { res->count = 0; res->overflow = 2; res->candidates = M; }
+        if (tid == 0) {
+            res->count = 0; res->overflow = 2; res->candidates = M;
+            if (xc.dst) xc.dst[0] = -1;  // duplicate keys: every rank reports the error after the exchange
+        }
     } else {
-        rerank_and_emit(xo, xr, M, k, ix, nullptr, res, true);
+        rerank_and_emit(xo, xr, M, k, ix, nullptr, res, true, xc);
     }
     publish_result(res, seq);
 }
@@ -1853,7 +1866,7 @@ int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu) {
 hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, const double* qptr,
                                   const lbh_qarg& qa, int k, int has_since,
                                   int64_t since_ms, uint64_t tag_mask, int grid, int nt, int seq, float margin,
-                                  hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+                                  hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const lbh_xchg* xc) {
     hipError_t e;
     if (ev0) (void)hipEventRecord(ev0, s);
     const dim3 g(grid), b(LBH_SCAN_THREADS);
@@ -1877,18 +1890,19 @@ hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const uint16_t* emb16
     if (ev1) (void)hipEventRecord(ev1, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, qptr, qa, k, ws.cand, ws.flags, ws.result_dev, seq, margin);
+    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, qptr, qa, k, ws.cand, ws.flags, ws.result_dev, seq, margin,
+                                                 xc ? *xc : lbh_xchg{nullptr, 0, 0});
     return hipGetLastError();
 }
 
 hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
                                    const lbh_qarg& qa, int k, int has_since,
                                    int64_t since_ms, uint64_t tag_mask, const lbh_cursor& cur, int grid, int seq,
-                                   hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+                                   hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const lbh_xchg* xc, const int32_t* gate) {
     hipError_t e;
     if (ev0) (void)hipEventRecord(ev0, s);
     const dim3 g(grid), b(LBH_SCAN_THREADS);
-#define LBH_XSCAN_ARGS ix, qptr, qa, k, since_ms, tag_mask, cur, ws.xcand_ord, ws.xcand_row, ws.flags, nullptr
+#define LBH_XSCAN_ARGS ix, qptr, qa, k, since_ms, tag_mask, cur, ws.xcand_ord, ws.xcand_row, ws.flags, gate
     if (has_since && tag_mask) scan_exact_kernel<true, true><<<g, b, 0, s>>>(LBH_XSCAN_ARGS);
     else if (has_since) scan_exact_kernel<true, false><<<g, b, 0, s>>>(LBH_XSCAN_ARGS);
     else if (tag_mask) scan_exact_kernel<false, true><<<g, b, 0, s>>>(LBH_XSCAN_ARGS);
@@ -1897,7 +1911,24 @@ hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace&
     if (ev1) (void)hipEventRecord(ev1, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    select_exact_kernel<<<1, SEL_THREADS, 0, s>>>(ix, k, ws.xcand_ord, ws.xcand_row, ws.flags, ws.result_dev, seq, nullptr);
+    select_exact_kernel<<<1, SEL_THREADS, 0, s>>>(ix, k, ws.xcand_ord, ws.xcand_row, ws.flags, ws.result_dev, seq, gate,
+                                                  xc ? *xc : lbh_xchg{nullptr, 0, 0});
+    return hipGetLastError();
+}
+
+namespace {
+// gathered lists: device memory -> device-mapped host memory, then the completion ticket (system-scope release)
+__global__ void xchg_publish_kernel(const int64_t* __restrict__ recv, int64_t* __restrict__ host, int n_words, int32_t* ticket, int seq) {
+    for (int i = threadIdx.x; i < n_words; i += blockDim.x) host[i] = recv[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
+hipError_t lbh_launch_xchg_publish(const int64_t* recv_dev, int64_t* recv_host_dev, int n_words, int32_t* ticket_host_dev, int seq,
+                                   hipStream_t s) {
+    xchg_publish_kernel<<<1, 256, 0, s>>>(recv_dev, recv_host_dev, n_words, ticket_host_dev, seq);
     return hipGetLastError();
 }
 
@@ -1967,7 +1998,7 @@ hipError_t lbh_launch_search_noalloc(void* scratch_ptr, const lbh_dev_index& ix,
         else scan_f32_kernel<false, false, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
     }
 #undef LBH_NA_ARGS
-    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, nullptr, qa, k, cand, flags, res, 1, margin);
+    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, nullptr, qa, k, cand, flags, res, 1, margin, lbh_xchg{nullptr, 0, 0});
     // mass near-ties (res->overflow == 1): the exact fp64 path decides; both kernels return at once otherwise.  No host
     // round trip in between, so the whole sequence is stream-ordered.
     lbh_cursor cur;
@@ -1979,7 +2010,7 @@ hipError_t lbh_launch_search_noalloc(void* scratch_ptr, const lbh_dev_index& ix,
     else if (tag_mask) scan_exact_kernel<false, true><<<gx, b, 0, s>>>(LBH_NAX_ARGS);
     else scan_exact_kernel<false, false><<<gx, b, 0, s>>>(LBH_NAX_ARGS);
 #undef LBH_NAX_ARGS
-    select_exact_kernel<<<1, SEL_THREADS, 0, s>>>(ix, k, xord, xrow, flags, res, 2, &res->overflow);
+    select_exact_kernel<<<1, SEL_THREADS, 0, s>>>(ix, k, xord, xrow, flags, res, 2, &res->overflow, lbh_xchg{nullptr, 0, 0});
     export_result_kernel<<<1, LBH_MAX_PAGE, 0, s>>>(res, out_rows_dev, out_scores_dev, out_count_dev);
     return hipGetLastError();
 }

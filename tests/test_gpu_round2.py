@@ -224,3 +224,39 @@ def test_in_place_tag_edits_reach_the_device_mask(hip):
         assert g.compile("alpha", tags=tags) == og.compile("alpha", tags=tags), tags
     assert g.compile("alpha") == og.compile("alpha")
     assert g.claims["a2"].to_dict()["tags"] == ["x"] and type(g.claims["a2"].to_dict()["tags"]) is list
+
+
+def test_sharded_search_behind_the_c_abi_single_rank(hip):
+    """lbh_comm_* + lbh_index_search_sharded with a one-rank communicator on the one GPU of this box: the whole call
+    sequence of the multi-GPU query (select kernel writes the packed list to device memory, RCCL all-gather on the
+    library's stream, publish to mapped host memory, merge) must return exactly what lbh_index_search_shard returns --
+    fast path, the gated exact path (all-ties query), filters, top_k beyond one page, an empty shard."""
+    from lbm_amd import synth
+    ch = synth.make_chunk(0, 60_000, seed=9, real_sha_keys=False, dup_frac=0.01)
+    ix = hip.Index()
+    ids = ix.add_texts(ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)
+    ix.retract_many(ids[ch.retracted])
+    comm = hip.Comm(hip.comm_unique_id(), 0, 1)
+    try:
+        qv = hip.embed_batch(synth.make_queries(5, seed=3) + [ch.text(77), ""])
+        p50 = int(ch.created_ms[ch.n // 2])
+        st = hip.Stats()
+        for smode in (0, 1):
+            hip.set_option("scan_mode", smode)
+            for q in qv:
+                for k, since, tm in ((8, hip.SINCE_NONE, 0), (64, p50, 0), (1, hip.SINCE_NONE, 0xF0), (200, hip.SINCE_NONE, 0), (0, p50, 0)):
+                    wi, ws, wk = ix.search_shard(q, k, since, tm)
+                    gi, gs, gk = ix.search_sharded(comm, q, k, since, tm, st)
+                    assert gi.tolist() == wi.tolist(), (smode, k, since, tm)   # world 1, rank 0: global id == local id
+                    assert gs.tobytes() == ws.tobytes() and gk.tobytes() == wk.tobytes()
+                    gi2, _, _ = ix.search_sharded(comm, q, k, since, tm, None, gid_mul=8, gid_add=3)
+                    assert gi2.tolist() == (wi * 8 + 3).tolist()
+        hip.set_option("scan_mode", 0)
+        empty = hip.Index()
+        gi, gs, gk = empty.search_sharded(comm, qv[0], 8)
+        assert gi.shape[0] == 0
+        empty.close()
+    finally:
+        hip.set_option("scan_mode", 0)
+        comm.close()
+        ix.close()
