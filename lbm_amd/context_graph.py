@@ -20,10 +20,16 @@ How the mirror works
     is added (``add_claim``) or first scored; later edits of ``Claim.text`` do
     not re-embed; ``retract`` drops the vector (:89); flipping ``retracted`` or
     deleting a dict entry by hand keeps it ("parked" on the host as fp64 bits).
-  * Tie-break keys: a 64-char lowercase-hex hash is stored as its 32 raw bytes
-    (byte order == str order).  If any other string is used as a hash, the graph
-    switches to rank keys: hashes are ranked with Python's own ``str`` order --
-    the order lb/context_graph.py:120 sorts by -- and the ranks become the keys.
+  * Tie-break keys (32 bytes per claim, compared as big-endian integers; they must
+    order like Python ``str``, which lb/context_graph.py:120 sorts by).  Three modes:
+    "hex"  every hash is 64 lowercase hex chars (what the CAS produces): the 32 raw
+           bytes (byte order == str order);
+    "raw"  every hash is at most 32 UTF-8 bytes without NUL (the reference's tests
+           use "old", "new", "h1"): the UTF-8 bytes, zero-padded (UTF-8 byte order ==
+           code-point order, and without NUL the padding cannot tie two hashes);
+    "rank" anything else, or a mix: hashes are ranked with Python's own ``str``
+           order and the ranks become the keys (rewritten after every change:
+           O(n log n) host work per sync, see INTEGRATION.md Limits).
 """
 from __future__ import annotations
 
@@ -138,6 +144,52 @@ class Claim:  # lb/context_graph.py:10-43
         )
 
 
+def format_context(query: str, chosen: Sequence[Tuple[str, Sequence[str]]]) -> str:
+    """lb/context_graph.py:122-133 on (text, tags) pairs."""
+    lines = ["Context slice", f"Query: {query}", ""]
+    for i, (text, tags) in enumerate(chosen, 1):
+        tag_str = (", ".join(tags)) if tags else ""
+        if tag_str:
+            lines.append(f"{i}. {text}  [tags: {tag_str}]")
+        else:
+            lines.append(f"{i}. {text}")
+    return "\n".join(lines).strip() + "\n"
+
+
+class LazyContext:
+    """Result of a ``lazy=True`` compile: the ranked claim hashes are ready, the context text (lb/context_graph.py:122-133)
+    is put together on first use -- off the query's critical path, in whatever thread asks for it.  The chosen claims'
+    text and tags are captured when the query ran, so the text is what an eager call would have returned then.
+    Unpacks like the reference's result: ``text, hashes = result``."""
+
+    __slots__ = ("query", "claim_hashes", "_chosen", "_text")
+
+    def __init__(self, query: str, hashes: List[str], chosen: List[Tuple[str, Tuple[str, ...]]]) -> None:
+        self.query, self.claim_hashes, self._chosen, self._text = query, hashes, chosen, None
+
+    @property
+    def context(self) -> str:
+        if self._text is None:
+            self._text = format_context(self.query, self._chosen)
+        return self._text
+
+    def __iter__(self):
+        yield self.context
+        yield self.claim_hashes
+
+    def __len__(self) -> int:
+        return 2
+
+    def __getitem__(self, i):
+        return (self.context, self.claim_hashes)[i]
+
+    def __eq__(self, other) -> bool:
+        return tuple(self) == (tuple(other) if isinstance(other, (tuple, list, LazyContext)) else other)
+
+    def __repr__(self) -> str:
+        return f"LazyContext(query={self.query!r}, claim_hashes={self.claim_hashes!r})"
+
+
 class _ClaimDict(dict):
     """``ContextGraph.claims``: a dict that reports which hashes changed."""
 
@@ -243,7 +295,9 @@ class _EmbeddingCacheView:
         if v.shape != (_hip.DIM,):
             raise ValueError("embedding must have 64 components")
         # what lbh_index_add would refuse is refused here, at the assignment, not at some later sync
-        if not np.all(np.isfinite(v)) or not float(np.sqrt(np.sum(v * v))) <= 1e15:
+        with np.errstate(over="ignore"):
+            too_big = not float(np.sqrt(np.sum(v * v))) <= 1e15
+        if not np.all(np.isfinite(v)) or too_big:
             raise ValueError("embedding must be finite with a norm of at most 1e15")
         g._drop_row(h, park=False)
         g._parked[h] = v
@@ -305,7 +359,7 @@ class ContextGraph:
         self._discard: Dict[str, None] = {}          # hashes whose cached vector retract() / add_claim() dropped since the last sync
         self._tag_bits: Dict[str, int] = {}
         self._tag_overflow = False
-        self._rank_keys = False
+        self._key_mode = "hex"   # "hex" | "raw" | "rank": how claim hashes become 32-byte ordering keys (module docstring)
         self._keys_stale = False
         self._seq_of: Dict[str, int] = {}      # hash -> position stamp in the ``claims`` dict order
         self._next_seq = 0
@@ -326,6 +380,10 @@ class ContextGraph:
     def _touch(self, h: str) -> None:
         self._dirty[h] = None
 
+    def _owns(self, h: str) -> bool:
+        """Whether this graph's device index scans claim ``h`` (always, except in a claim-sharded graph)."""
+        return True
+
     def _tagmask(self, tags: Iterable[str]) -> int:
         m = 0
         for t in tags:
@@ -339,13 +397,33 @@ class ContextGraph:
             m |= 1 << b
         return m
 
+    @staticmethod
+    def _raw_key(h) -> Optional[bytes]:
+        """Zero-padded UTF-8 image of a short hash, or None if it does not order like the string (too long, NUL inside)."""
+        if not isinstance(h, str):
+            return None
+        b = h.encode("utf-8", "surrogatepass")
+        if len(b) > _hip.KEY_BYTES or b"\x00" in b:
+            return None
+        return b.ljust(_hip.KEY_BYTES, b"\x00")
+
     def _key_bytes(self, h: str) -> bytes:
-        if not self._rank_keys and isinstance(h, str) and _HEX64.match(h):
-            return bytes.fromhex(h)
-        if not self._rank_keys:
-            self._rank_keys = True
+        if self._key_mode == "hex":
+            if isinstance(h, str) and _HEX64.match(h):
+                return bytes.fromhex(h)
+            # first hash that is not a CAS hash: an empty device index can still switch to raw keys
+            self._key_mode = "raw" if not self._id_of and self._raw_key(h) is not None else "rank"
+        if self._key_mode == "raw":
+            k = self._raw_key(h)
+            if k is not None:
+                return k
+            self._key_mode = "rank"
         self._keys_stale = True
         return b"\x00" * _hip.KEY_BYTES  # placeholder until _refresh_rank_keys
+
+    @property
+    def _rank_keys(self) -> bool:
+        return self._key_mode == "rank"
 
     @_locked
     def _refresh_rank_keys(self) -> None:
@@ -435,6 +513,9 @@ class ContextGraph:
                         self._keys_stale = True
                     self._meta[h] = (cm, tm)
                 continue
+            if not self._owns(h):  # claim-sharded graph: another rank scans this claim
+                self._pending_text.pop(h, None)
+                continue
             if h in self._parked:
                 new_vec.append((h, self._parked[h], c))
             else:
@@ -470,14 +551,18 @@ class ContextGraph:
 
     def _keys_of(self, hs: Sequence[str]) -> np.ndarray:
         """32-byte ordering keys of a batch of hashes (one bulk hex decode when they are all sha256 hex)."""
-        if not self._rank_keys:
+        if self._key_mode == "hex":
             try:
                 joined = "".join(hs)
                 if len(joined) == 64 * len(hs) and _HEXRUN.match(joined) and all(len(h) == 64 for h in hs):
                     return np.frombuffer(bytes.fromhex(joined), dtype=np.uint8)
             except TypeError:
                 pass
-        return np.frombuffer(b"".join(self._key_bytes(h) for h in hs), dtype=np.uint8)
+        mode = self._key_mode
+        keys = [self._key_bytes(h) for h in hs]
+        if self._key_mode != mode:  # the batch itself changed the mode: every key of the batch under the final one
+            keys = [self._key_bytes(h) for h in hs]
+        return np.frombuffer(b"".join(keys), dtype=np.uint8)
 
     # ------------------------------------------------------------------ reference API
 
@@ -519,26 +604,27 @@ class ContextGraph:
             self._pending_text.pop(claim_hash, None)
 
     def compile(
-        self, query: str, *, top_k: int = 8, since_ms: Optional[int] = None, tags: Optional[Sequence[str]] = None
+        self, query: str, *, top_k: int = 8, since_ms: Optional[int] = None, tags: Optional[Sequence[str]] = None,
+        lazy: bool = False,
     ) -> Tuple[str, List[str]]:
         """Compile context slice from claims (lb/context_graph.py:91-133).
 
-        ``tags`` (extension, default off): keep only claims carrying at least one of these tags.
+        Extensions, both off by default: ``tags`` keeps only claims carrying at least one of these tags;
+        ``lazy=True`` returns a ``LazyContext`` (hashes now, text formatted on first use).
         """
         chosen, _ = self._rank(query, top_k, since_ms, tags)
+        if lazy:
+            return self._lazy(query, chosen)
         return self._format(query, chosen), chosen
 
     def _format(self, query: str, chosen: List[str]) -> str:
         """lb/context_graph.py:122-133."""
-        lines = ["Context slice", f"Query: {query}", ""]
-        for i, h in enumerate(chosen, 1):
-            c = self.claims[h]
-            tag_str = (", ".join(c.tags)) if c.tags else ""
-            if tag_str:
-                lines.append(f"{i}. {c.text}  [tags: {tag_str}]")
-            else:
-                lines.append(f"{i}. {c.text}")
-        return "\n".join(lines).strip() + "\n"
+        claims = self.claims
+        return format_context(query, [(claims[h].text, claims[h].tags) for h in chosen])
+
+    def _lazy(self, query: str, chosen: List[str]) -> LazyContext:
+        claims = self.claims
+        return LazyContext(query, chosen, [(claims[h].text, tuple(claims[h].tags)) for h in chosen])
 
     def compile_scored(self, query: str, *, top_k: int = 8, since_ms: Optional[int] = None,
                        tags: Optional[Sequence[str]] = None, stats: Optional[_hip.Stats] = None
@@ -575,6 +661,10 @@ class ContextGraph:
         if empty:
             return [], []
         index = self._index  # opens the HIP backend even for an empty graph: no silent CPU path
+        return self._search_text(index, query, k, since, tag_mask, stats)
+
+    def _search_text(self, index, query: str, k: int, since: int, tag_mask: int, stats) -> Tuple[List[str], List[float]]:
+        """Device part of ``compile``: embed(query) + scan + exact top-k -> (hashes, fp64 scores)."""
         if k == 0 or not self._id_of:
             return [], []
         ids, scores, _ = index.search_text(query, k, since, tag_mask, stats)
@@ -622,10 +712,10 @@ class ContextGraph:
 
     @_locked
     def compile_many(self, queries: Sequence[str], *, top_k: int = 8, since_ms: Optional[int] = None,
-                     tags: Optional[Sequence[str]] = None) -> List[Tuple[str, List[str]]]:
+                     tags: Optional[Sequence[str]] = None, lazy: bool = False) -> List[Tuple[str, List[str]]]:
         """Batched ``compile`` (extension; the reference has no batched entry): the queries are embedded
         in one K1 launch and ranked in one pass over the claim matrix on the matrix cores (K3).  Each
-        element equals ``compile(q, top_k=..., since_ms=..., tags=...)`` exactly."""
+        element equals ``compile(q, top_k=..., since_ms=..., tags=...)`` exactly (``lazy=True``: as ``LazyContext``)."""
         self._sync()
         k = max(0, int(top_k))
         since, tag_mask, empty = self._filters(since_ms, tags)
@@ -637,6 +727,8 @@ class ContextGraph:
             qv = _hip.embed_batch(list(queries))
             ids, _, cnt = index.search(qv, k, since, tag_mask)
             ranked = [[self._hash_of[i] for i in ids[j, : int(cnt[j])].tolist()] for j in range(len(queries))]
+        if lazy:  # hashes now; each context text is formatted when (and if) its caller reads it
+            return [self._lazy(q, chosen) for q, chosen in zip(queries, ranked)]
         return [(self._format(q, chosen), chosen) for q, chosen in zip(queries, ranked)]
 
     @_locked

@@ -7,8 +7,10 @@ raises ``NodeError``, otherwise exactly ``graph.compile(...)`` -- is testable he
 """
 from __future__ import annotations
 
+import json
+import os
 from dataclasses import dataclass, field
-from typing import Any, Dict, List, Optional, Tuple
+from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
 
 from .context_graph import ContextGraph
 
@@ -19,9 +21,31 @@ class NodeError(Exception):  # lb/node.py:33
 
 @dataclass
 class Group:
-    """Holds what compile_context touches of lb/group.py:16 -- the graph."""
+    """Holds what compile_context touches of lb/group.py:16 -- the graph -- and the graph half of its
+    save / load (lb/group.py:30-55: ``graph.json`` = ``ContextGraph.snapshot()``; chain.json is out of scope)."""
     group_id: str
     graph: ContextGraph = field(default_factory=ContextGraph)
+
+    def save_graph(self, root: str) -> str:
+        """lb/group.py:40-44 for the graph: ``<root>/graph.json``, written to a temporary file and renamed."""
+        os.makedirs(root, exist_ok=True)
+        path = os.path.join(root, "graph.json")
+        tmp = path + ".tmp"
+        with open(tmp, "w", encoding="utf-8") as f:
+            json.dump(self.graph.snapshot(), f)
+        os.replace(tmp, path)
+        return path
+
+    @staticmethod
+    def load_graph(group_id: str, root: str) -> "Group":
+        """lb/group.py:47-55 for the graph: ``from_snapshot`` of graph.json when it exists, else an empty graph.  The
+        reference re-embeds every live claim here, one Python ``embed`` at a time; this mirror defers it to ONE K1
+        launch at the first query (lbm_amd/context_graph.py:from_snapshot)."""
+        path = os.path.join(root, "graph.json")
+        if os.path.exists(path):
+            with open(path, "r", encoding="utf-8") as f:
+                return Group(group_id, ContextGraph.from_snapshot(json.load(f)))
+        return Group(group_id)
 
 
 class RetrievalNode:
@@ -39,11 +63,55 @@ class RetrievalNode:
         return g
 
     def compile_context(self, group_id: str, query: str, *, top_k: int = 8,
-                        since_ms: Optional[int] = None) -> Tuple[str, List[str]]:
-        """lb/node.py:718-734: a pure delegate; takes no lock, like the reference."""
+                        since_ms: Optional[int] = None, lazy: bool = False) -> Tuple[str, List[str]]:
+        """lb/node.py:718-734: a pure delegate; takes no lock, like the reference.  ``lazy=True`` (extension): a
+        ``LazyContext`` whose text is formatted on first use."""
         g = self._require_group(group_id)
+        if lazy:
+            return g.graph.compile(query, top_k=top_k, since_ms=since_ms, lazy=True)
         slice_text, chosen = g.graph.compile(query, top_k=top_k, since_ms=since_ms)
         return slice_text, chosen
+
+    def rebuild_group_graph(self, group_id: str, txs: Iterable[Dict[str, Any]]) -> None:
+        """lb/node.py:486-515 without the chain and the CAS (out of scope): ``txs`` is the group's transaction stream
+        with the claim objects already resolved -- ``{"type": "claim", "artifact_hash": h, "object": {...}}`` (what
+        ``cas.get_json(h)`` returns; a missing / non-dict object skips the claim like a CAS miss does) and
+        ``{"type": "retract", "claim_hash": h}``.  A NEW graph replaces the group's, exactly as in the reference; every
+        claim it keeps is vectorised in one K1 launch at the first query and the retracts never reach the device."""
+        g = self._require_group(group_id)
+        new_graph = ContextGraph()
+        for tx in txs:
+            t = tx.get("type")
+            if t == "claim":
+                h = tx.get("artifact_hash")
+                obj = tx.get("object")
+                if isinstance(h, str) and isinstance(obj, dict):
+                    try:
+                        new_graph.add_claim(
+                            h,
+                            text=str(obj.get("text", "")),
+                            tags=list(obj.get("tags", [])),
+                            evidence=list(obj.get("evidence", [])),
+                            created_ms=int(obj.get("created_ms", 0) or 0),
+                            parent_hash=obj.get("parent_hash"),
+                        )
+                    except Exception:  # noqa: BLE001  (the reference logs and skips the claim, lb/node.py:508-510)
+                        continue
+            elif t == "retract":
+                ch = tx.get("claim_hash")
+                if isinstance(ch, str):
+                    new_graph.retract(ch)
+        g.graph = new_graph
+
+    def compile_context_many(self, group_id: str, queries: Sequence[str], *, top_k: int = 8,
+                             since_ms: Optional[int] = None, lazy: bool = False) -> List[Tuple[str, List[str]]]:
+        """Batched ``compile_context`` (the reference has no batched entry -- its callers, e.g. the
+        MCP tool at lb/mcp.py:271-279, loop): same group check, then every query is ranked in ONE pass over the group's
+        claim matrix on the matrix cores (K3).  Element i equals ``compile_context(group_id, queries[i], ...)``.
+        ``lazy=True`` returns ``LazyContext`` objects: claim hashes at once, the context text formatted when it is read
+        (lb/context_graph.py:122-133 leaves the query's critical path)."""
+        g = self._require_group(group_id)
+        return g.graph.compile_many(queries, top_k=top_k, since_ms=since_ms, lazy=lazy)
 
     def get_recent_claims(self, group_id: str, since_ms: int, *, limit: int = 100) -> List[Dict[str, Any]]:
         """lb/node.py:736-762: claims created at or after ``since_ms``, newest first, at most ``limit``.

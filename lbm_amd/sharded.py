@@ -11,9 +11,12 @@ entries with the same comparator.  No other collective is on the data path.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+import zlib
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
+
+from .context_graph import _HEX64, ContextGraph
 
 ENTRY_WORDS = 6  # score bits, global id, 4 key words  (48 bytes)
 
@@ -119,3 +122,93 @@ class ShardedSearcher:
             b.recv_host.copy_(b.recv_dev, non_blocking=True)
             torch.cuda.current_stream(b.recv_dev.device).synchronize()
         return self._merge(b.recv_np, k)
+
+
+def owner_of(claim_hash: str, world: int) -> int:
+    """Rank that scans a claim: a stable function of the hash alone (CRC-32 of its UTF-8 bytes), so every rank routes
+    every claim the same way without talking to anyone."""
+    return zlib.crc32(claim_hash.encode("utf-8", "surrogatepass")) % world
+
+
+class ShardedContextGraph(ContextGraph):
+    """``ContextGraph`` over the GPUs of a node, one process per GPU (SPMD): every rank applies the SAME sequence of
+    ``add_claim`` / ``retract`` / dict edits -- the way every node of the reference replays the same chain -- and keeps the
+    host-side ``claims`` dict in full, but only the claims it owns (``owner_of(hash)``) get a row in its GPU's index.
+    ``compile`` is collective: each rank ranks its shard (same kernels as the single-GPU graph), the ranks exchange their
+    top-k lists once -- ``lbh_index_search_sharded`` (RCCL all-gather over xGMI inside liblbhip) when a ``comm`` is given,
+    else ``torch.distributed`` on ``group`` (gloo in the CPU tests) -- and merge them with the reference's comparator, so
+    every rank returns exactly what one ``ContextGraph`` holding all claims returns (lb/context_graph.py:91-133).
+
+    Claim hashes must order like their 32-byte keys on every rank: either all 64-hex CAS hashes or all short strings
+    (<= 32 UTF-8 bytes, no NUL).  Anything else raises ``ValueError`` at the next query (rank keys are private to one
+    index and cannot be merged across shards)."""
+
+    def __init__(self, rank: int, world: int, *, comm=None, group=None, _index_factory=None, _embed=None) -> None:
+        super().__init__()
+        if not 0 <= int(rank) < int(world):
+            raise ValueError("rank must be in [0, world)")
+        self.rank, self.world = int(rank), int(world)
+        self._comm, self._group = comm, group
+        self._index_factory, self._embed_fn = _index_factory, _embed
+        self._seen_hex = self._seen_raw = False
+        self._searcher: Optional[ShardedSearcher] = None
+
+    # -- hooks of the base class -------------------------------------------------------------------------------------
+    @property
+    def _index(self):
+        if self._index_obj is None and self._index_factory is not None:
+            self._index_obj = self._index_factory()  # CPU tests: an oracle-backed stand-in
+        return ContextGraph._index.fget(self)
+
+    def _owns(self, h: str) -> bool:
+        # called for every live claim of a sync, on every rank, before ownership decides anything: the key mode has to
+        # follow ALL hashes of the graph, not just this rank's, or the ranks' keys would not be comparable
+        if isinstance(h, str) and _HEX64.match(h):
+            self._seen_hex = True
+        elif self._raw_key(h) is not None:
+            self._seen_raw = True
+        else:
+            raise ValueError(f"claim-sharded graph: hash {h!r} is neither 64 hex chars nor <= 32 UTF-8 bytes without NUL")
+        if self._seen_hex and self._seen_raw:
+            raise ValueError("claim-sharded graph: 64-hex hashes and short free-form hashes cannot be mixed "
+                             "(their 32-byte keys would not order like the strings)")
+        self._key_mode = "hex" if self._seen_hex else "raw"
+        return owner_of(h, self.world) == self.rank
+
+    def _hash_of_key(self, key: np.ndarray) -> str:
+        b = bytes(key)
+        return b.hex() if self._key_mode == "hex" else b.rstrip(b"\x00").decode("utf-8", "surrogatepass")
+
+    def _rank(self, query, top_k, since_ms, tags, stats=None) -> Tuple[List[str], List[float]]:
+        """Collective: every rank must call it with the same arguments."""
+        from . import _hip
+        with self._lock:
+            self._sync()
+            k = max(0, int(top_k))
+            since, tag_mask, empty = self._filters(since_ms, tags)
+            index = self._index
+            if k == 0:
+                return [], []  # on every rank alike: no exchange for an empty request
+            if empty:  # nothing on THIS rank can pass (no claim of this shard carries the tag): still take part in the exchange
+                since, tag_mask = _hip.INT64_MAX, 0
+            qv = (self._embed_fn or (lambda t: _hip.embed_batch([t])[0]))(query)
+            if self._comm is not None:
+                _, scores, keys = index.search_sharded(self._comm, qv, k, since, tag_mask, stats, gid_mul=1, gid_add=0)
+            else:
+                if self._searcher is None:
+                    self._searcher = ShardedSearcher(self._local_search, self.rank, self.world, group=self._group, always_gather=True)
+                _, scores, kw = self._searcher.search(qv, k, since, tag_mask)
+                keys = np.ascontiguousarray(kw).astype(">u8").view(np.uint8).reshape(-1, 32)
+            return [self._hash_of_key(keys[i]) for i in range(len(scores))], [float(x) for x in scores]
+
+    def _local_search(self, q, k, since_ms, tag_mask):
+        if not self._id_of:
+            return np.zeros(0, np.uint64), np.zeros(0), np.zeros((0, 32), np.uint8)
+        return self._index.search_shard(q, k, since_ms, tag_mask)
+
+    def compile_many(self, queries: Sequence[str], *, top_k: int = 8, since_ms=None, tags=None, lazy: bool = False):
+        """Collective; one exchange per query (the batched MFMA path is per GPU and has no sharded form yet)."""
+        return [self.compile(q, top_k=top_k, since_ms=since_ms, tags=tags, lazy=lazy) for q in queries]
+
+    def recent(self, since_ms, limit=100):
+        raise NotImplementedError("get_recent_claims is not sharded: ask a single-GPU ContextGraph")

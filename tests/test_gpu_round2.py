@@ -260,3 +260,126 @@ def test_sharded_search_behind_the_c_abi_single_rank(hip):
         hip.set_option("scan_mode", 0)
         comm.close()
         ix.close()
+
+
+def test_sharded_context_graph_on_the_gpu_single_rank(hip, golden_synth):
+    """ShardedContextGraph with the real backend: a one-rank RCCL communicator behind the C ABI, device K1 for the query,
+    lbh_index_search_sharded for the ranking -> the reference's golden answers."""
+    from lbm_amd.sharded import ShardedContextGraph
+    d = golden_synth
+    comm = hip.Comm(hip.comm_unique_id(), 0, 1)
+    try:
+        g = ShardedContextGraph(0, 1, comm=comm)
+        for i in range(d["n"]):
+            tags = ["t%02d" % j for j in range(64) if (d["tagmask"][i] >> j) & 1]
+            g.add_claim(d["hashes"][i], d["texts"][i], tags, created_ms=d["created_ms"][i])
+        for i in range(d["n"]):
+            if d["retracted"][i]:
+                g.retract(d["hashes"][i])
+        for r in d["results"][::3]:
+            kw = {"top_k": r["top_k"]}
+            if r["since_ms"] is not None:
+                kw["since_ms"] = r["since_ms"]
+            text, hs = g.compile(r["query"], **kw)
+            assert hs == r["hashes"], (r["query"], kw)
+            assert hashlib.sha256(text.encode()).hexdigest() == r["context_sha256"]
+            assert hexes(g.compile_scored(r["query"], **kw)[1]) == r["scores"]
+    finally:
+        comm.close()
+
+
+def test_node_level_batched_entry_and_lazy_formatting(hip):
+    """RetrievalNode.compile_context_many == [compile_context(q) ...] (K3 behind it), and lazy=True hands
+    the hashes back before the context text exists; the text, once read, is what the eager call returned."""
+    from lbm_amd import synth
+    from lbm_amd.context_graph import LazyContext
+    from lbm_amd.node import NodeError, RetrievalNode
+    ch = synth.make_chunk(0, 6000, seed=21, dup_frac=0.02)
+    node = RetrievalNode()
+    gid = node.create_group("g")
+    g = node.groups[gid].graph
+    texts, hashes = ch.texts(), ch.hashes()
+    for i in range(ch.n):
+        g.add_claim(hashes[i], texts[i], ch.tags(i), created_ms=int(ch.created_ms[i]))
+    qs = synth.make_queries(20, seed=5) + [texts[9], "", "nothing matches this"]
+    since = int(ch.created_ms[3000])
+    for kw in ({}, {"top_k": 16, "since_ms": since}, {"top_k": 3}, {"top_k": 0}):
+        want = [node.compile_context(gid, q, **kw) for q in qs]
+        assert node.compile_context_many(gid, qs, **kw) == want
+        lazy = node.compile_context_many(gid, qs, lazy=True, **kw)
+        assert all(isinstance(x, LazyContext) and x._text is None for x in lazy)
+        assert [x.claim_hashes for x in lazy] == [w[1] for w in want]
+        g.claims[hashes[0]].text = "edited after the query"  # a lazy text shows the claims as they were at query time
+        assert [tuple(x) for x in lazy] == want
+        g.claims[hashes[0]].text = texts[0]
+    one = node.compile_context(gid, qs[0], lazy=True)
+    assert isinstance(one, LazyContext) and (one.context, one.claim_hashes) == node.compile_context(gid, qs[0])
+    text, hs = one
+    assert (text, hs) == node.compile_context(gid, qs[0])
+    with pytest.raises(NodeError, match="unknown group_id nope"):
+        node.compile_context_many("nope", ["q"])
+
+
+def test_raw_key_mode_and_rank_key_fallback(hip):
+    """Short free-form hashes (the reference's tests: "old", "new", "h1") take order-preserving raw keys -- no per-sync
+    re-ranking; anything else (over 32 bytes, NUL inside, mixed with CAS hashes) falls back to rank keys.  Ties on score
+    must break exactly like Python's str order in every mode."""
+    from lbm_amd.context_graph import ContextGraph
+    dup = "the same exact text appears many times"
+    cases = {
+        "raw": ["zzz", "Zzz", "a", "aa", "é", "0", "00", "claim_0002", "claim_0001", "~", "a" * 32, "日本", "", "a b"],
+        "rank_long": ["zzz", "a" * 33, "a" * 32, "b"],
+        "rank_nul": ["a", "a\x00", "a\x00\x00", "b"],
+        "rank_mixed": ["f" * 64, "zz", "0" * 64, "a"],
+        "hex": ["f" * 64, "0" * 63 + "1", "a" * 64, "b" * 64],
+    }
+    for name, keys in cases.items():
+        g, og = ContextGraph(), orc.OracleGraph()
+        for i, h in enumerate(keys):
+            for gg in (g, og):
+                gg.add_claim(h, dup if i % 3 else "something else", [], created_ms=i)
+            if i == 1:
+                assert g.compile("same text", top_k=10) == og.compile("same text", top_k=10)  # a query between the adds
+        for q in ("same text", "", "else"):
+            assert g.compile(q, top_k=20) == og.compile(q, top_k=20), (name, q)
+        assert g._key_mode == name.split("_")[0], (name, g._key_mode)
+        for gg in (g, og):
+            gg.retract(keys[0])
+            gg.add_claim("late" if name != "hex" else "c" * 64, dup, [], created_ms=99)
+        assert g.compile("same text", top_k=20) == og.compile("same text", top_k=20), name
+
+
+def test_group_graph_save_load_and_rebuild(hip, tmp_path, golden_snapshot):
+    """lb/group.py:30-55 (graph half) and lb/node.py:486-515: graph.json round trip and the rebuild from a resolved
+    transaction stream, both ending in one bulk K1 launch, against the reference's reloaded-graph results."""
+    import json as _json
+    from lbm_amd.node import Group, RetrievalNode
+    case = golden_snapshot[0]
+    g = _replay(case["ops"])
+    grp = Group("g1", g)
+    path = grp.save_graph(str(tmp_path))
+    assert _json.load(open(path)) == case["snapshot"]
+    loaded = Group.load_graph("g1", str(tmp_path))
+    for r in case["results"]:
+        kw = {k: r[k] for k in ("top_k", "since_ms") if k in r}
+        assert loaded.graph.compile(r["query"], **kw) == (r["context"], r["hashes"])
+    assert Group.load_graph("g2", str(tmp_path / "missing")).graph.compile("x") == ("Context slice\nQuery: x\n", [])
+    # rebuild: the same ops as a transaction stream (claims resolved to their objects, retracts by hash)
+    node = RetrievalNode()
+    node.create_group("g1")
+    txs, og = [], orc.OracleGraph()
+    for op in case["ops"]:
+        if op[0] == "add":
+            txs.append({"type": "claim", "artifact_hash": op[1], "object": {"text": op[2], "tags": op[3], "created_ms": op[4],
+                                                                            "parent_hash": op[5] if len(op) > 5 else None}})
+            og.add_claim(op[1], op[2], op[3], created_ms=op[4])
+        elif op[0] == "retract":
+            txs.append({"type": "retract", "claim_hash": op[1]})
+            og.retract(op[1])
+    txs.append({"type": "claim", "artifact_hash": "missing-from-cas", "object": None})
+    txs.append({"type": "vote", "x": 1})
+    old = node.groups["g1"].graph
+    node.rebuild_group_graph("g1", txs)
+    assert node.groups["g1"].graph is not old
+    for q in ("beta", "gamma delta", ""):
+        assert node.compile_context("g1", q, top_k=10) == og.compile(q, top_k=10)

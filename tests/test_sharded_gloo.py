@@ -112,3 +112,81 @@ def test_c_merge_equals_numpy_merge_on_random_lists():
         a, b = merge_gathered(g, k), merge_entries(g, k)
         assert a[1].tobytes() == b[1].tobytes() or np.array_equal(a[1], b[1])  # scores (+-0.0 may differ in bits only on ties)
         assert np.array_equal(a[2], b[2])  # key words: the order of the reference
+
+
+def _graph_worker(rank, world, port, out_q):
+    sys.path.insert(0, REPO)
+    import hashlib
+    import json
+    import torch.distributed as dist
+    from lbm_amd.sharded import ShardedContextGraph, owner_of
+    from oracle import lb_oracle as orc
+    from tests.oracle_index import OracleIndex
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ok = []
+    d = json.load(open(os.path.join(REPO, "tests", "golden", "synth2k.json")))["data"]
+    g = ShardedContextGraph(rank, world, _index_factory=OracleIndex, _embed=orc.embed_array)
+    for i in range(d["n"]):
+        tags = ["t%02d" % j for j in range(64) if (d["tagmask"][i] >> j) & 1]
+        g.add_claim(d["hashes"][i], d["texts"][i], tags, created_ms=d["created_ms"][i])
+    for i in range(d["n"]):
+        if d["retracted"][i]:
+            g.retract(d["hashes"][i])
+    for r in d["results"][::5]:  # the reference's own answers: hashes, fp64 score bits, context text
+        kw = {"top_k": r["top_k"]}
+        if r["since_ms"] is not None:
+            kw["since_ms"] = r["since_ms"]
+        text, hs = g.compile(r["query"], **kw)
+        _, sc = g.compile_scored(r["query"], **kw)
+        ok.append(hs == r["hashes"] and hashlib.sha256(text.encode()).hexdigest() == r["context_sha256"]
+                  and [float(x).hex() for x in sc] == r["scores"])
+    owned = sum(owner_of(h, world) == rank for h, r in zip(d["hashes"], d["retracted"]) if not r)
+    ok.append(g._index.size() == owned and 0 < owned < d["n"])  # only this rank's claims are on its device
+    # the tag extension and a lazily formatted result go through the same exchange
+    og = orc.OracleGraph()
+    for i in range(0, 300):
+        tags = ["t%02d" % j for j in range(64) if (d["tagmask"][i] >> j) & 1]
+        og.add_claim(d["hashes"][i], d["texts"][i], tags, created_ms=d["created_ms"][i])
+    g2 = ShardedContextGraph(rank, world, _index_factory=OracleIndex, _embed=orc.embed_array)
+    for h, c in og.claims.items():
+        g2.add_claim(h, c.text, c.tags, created_ms=c.created_ms)
+    for tags in (["t03"], ["t10", "t11"], ["nobody"]):
+        ok.append(g2.compile("w00001 w00002", top_k=16, tags=tags) == og.compile("w00001 w00002", top_k=16, tags=tags))
+    lazy = g2.compile("w00003", top_k=4, lazy=True)
+    ok.append(lazy.claim_hashes == og.compile("w00003", top_k=4)[1] and tuple(lazy) == og.compile("w00003", top_k=4))
+    ok.append(g2.compile_many(["w00001", ""], top_k=3) == [og.compile("w00001", top_k=3), og.compile("", top_k=3)])
+    # short free-form hashes (the reference's tests use "old" / "new"): raw keys, still mergeable
+    g3, og3 = ShardedContextGraph(rank, world, _index_factory=OracleIndex, _embed=orc.embed_array), orc.OracleGraph()
+    for i, h in enumerate(["old", "new", "h1", "zzz", "Zzz", "a", "aa", "é", "claim_0002", "claim_0001"]):
+        for gg in (g3, og3):
+            gg.add_claim(h, "the same exact text" if i % 2 else "Old data", ["data"], created_ms=1000 * i)
+    for q, kw in (("data", {"top_k": 10, "since_ms": 1500}), ("same text", {"top_k": 4}), ("", {"top_k": 10})):
+        ok.append(g3.compile(q, **kw) == og3.compile(q, **kw))
+    g3.add_claim("f" * 64, "a CAS hash among free-form ones", [], created_ms=5)
+    try:
+        g3.compile("data")
+        ok.append(False)
+    except ValueError:
+        ok.append(True)  # raised on every rank alike, before any collective
+    dist.barrier()
+    dist.destroy_process_group()
+    out_q.put((rank, ok))
+
+
+@pytest.mark.timeout(300)
+def test_sharded_context_graph_two_ranks_equals_reference_golden():
+    """Graph-level sharding (north_star: compile_context over a claim-sharded corpus returns hash-identical top-k):
+    two gloo ranks, each holding the claims it owns in an oracle-backed index, answer the reference's golden queries."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graph_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=200) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok in got:
+        assert len(ok) > 30 and all(ok), (rank, [i for i, x in enumerate(ok) if not x])
