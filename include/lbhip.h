@@ -81,6 +81,12 @@ int lbh_device_name(lbh_ctx* ctx, char* buf, int buflen);
  * LBH_BQ_MODE / LBH_SPIN_US. */
 int lbh_set_option(lbh_ctx* ctx, const char* name, int64_t value);
 
+/* Pinned (page-locked) host memory for the arrays handed to lbh_index_add / lbh_embed_batch (no reference counterpart:
+ * an ingest-rate helper).  From pinned buffers the text, offsets, timestamps, tag masks and keys cross PCIe by
+ * asynchronous DMA that overlaps the vectorising kernel; ordinary (pageable) buffers work everywhere, only slower. */
+int lbh_host_alloc(lbh_ctx* ctx, int64_t bytes, void** out_ptr);
+int lbh_host_free(lbh_ctx* ctx, void* ptr);
+
 /* ---- lb/latent.py ----------------------------------------------------------- */
 
 /* replaces lb/latent.py:41-57  embed(text, dim=64), batched.

@@ -28,7 +28,7 @@ LIB_PATH = os.environ.get("LBM_HIP_LIB") or os.path.join(_HERE, "liblbhip.so")  
 
 EXPORTS = [
     "lbh_init", "lbh_shutdown", "lbh_last_error", "lbh_version", "lbh_device_name", "lbh_set_option",
-    "lbh_embed_batch", "lbh_embed_batch_dim", "lbh_embed_batch_dev", "lbh_cosine",
+    "lbh_host_alloc", "lbh_host_free", "lbh_embed_batch", "lbh_embed_batch_dim", "lbh_embed_batch_dev", "lbh_cosine",
     "lbh_index_create", "lbh_index_destroy", "lbh_index_reserve", "lbh_index_add", "lbh_index_retract",
     "lbh_index_retract_many", "lbh_index_update_meta", "lbh_index_set_keys", "lbh_index_size", "lbh_index_get_embedding",
     "lbh_index_get_embeddings",
@@ -112,6 +112,8 @@ def load_library() -> ctypes.CDLL:
         L.lbh_device_name.argtypes = [_vp, ctypes.c_char_p, ctypes.c_int]
         L.lbh_set_option.argtypes = [_vp, ctypes.c_char_p, _i64]
         L.lbh_embed_batch.argtypes = [_vp, _vp, _vp, _i64, _vp]
+        L.lbh_host_alloc.argtypes = [_vp, _i64, ctypes.POINTER(_vp)]
+        L.lbh_host_free.argtypes = [_vp, _vp]
         L.lbh_embed_batch_dim.argtypes = [_vp, _vp, _vp, _i64, ctypes.c_int, _vp]
         L.lbh_embed_batch_dev.argtypes = [_vp, _vp, _vp, _i64, _i64, _vp, _vp]
         L.lbh_cosine.argtypes = [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(ctypes.c_double)]
@@ -211,6 +213,40 @@ def _since(since_ms) -> int:
 
 def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(_vp)
+
+
+class PinnedArray:
+    """A numpy array over page-locked host memory from ``lbh_host_alloc``: arrays handed to ``Index.add_texts`` /
+    ``add_vectors`` from here cross PCIe by asynchronous DMA.  ``.a`` is the array; keep the object alive while it is used."""
+
+    def __init__(self, shape, dtype) -> None:
+        self._L = load_library()
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+        p = _vp()
+        _check(self._L.lbh_host_alloc(context(), max(n * dt.itemsize, 1), ctypes.byref(p)))
+        self._p = p
+        buf = (ctypes.c_char * max(n * dt.itemsize, 1)).from_address(p.value)
+        self.a = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+
+    def close(self) -> None:
+        if getattr(self, "_p", None):
+            self.a = None
+            self._L.lbh_host_free(context(), self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pinned_like(arr: np.ndarray) -> PinnedArray:
+    """Copy of ``arr`` in pinned memory."""
+    p = PinnedArray(arr.shape, arr.dtype)
+    p.a[...] = arr
+    return p
 
 
 def pack_texts(texts: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:

@@ -40,10 +40,14 @@ int fail(int code, const char* fmt, ...) {
 
 }  // namespace
 
+#define LBH_ADD_SLICES 8  // most slices one lbh_index_add call is cut into
+
 struct lbh_ctx {
     int device = 0;
     int n_cu = 256;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;            // H2D copies of lbh_index_add's text slices (overlap with K1 on `stream`)
+    hipEvent_t copy_ev[LBH_ADD_SLICES] = {};
     std::string arch;
     int scan_blocks_per_cu = 2;  // tuning knobs (env LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT), see DESIGN.md
     int scan_nt = 1;
@@ -447,6 +451,9 @@ int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx) {
     if (const char* e3 = getenv("LBH_SPIN_US")) c->spin_us = std::max(0, std::min(1000000, atoi(e3)));
     hipError_t e0 = hipSetDevice(c->device);
     if (e0 == hipSuccess) e0 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e0 == hipSuccess) e0 = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    for (auto& ev : c->copy_ev)
+        if (e0 == hipSuccess) e0 = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     // with this device current: where ITS copy of the allocation-free entry point's scratch array lives
     if (e0 == hipSuccess) e0 = lbh_noalloc_init(&c->noalloc_scratch);
     if (e0 != hipSuccess || !c->noalloc_scratch) {
@@ -466,6 +473,9 @@ int lbh_shutdown(lbh_ctx* c) {
     if (c->d_off) (void)hipFree(c->d_off);
     if (c->d_vec) (void)hipFree(c->d_vec);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (auto& ev : c->copy_ev)
+        if (ev) (void)hipEventDestroy(ev);
     delete c;
     return LBH_OK;
 }
@@ -485,6 +495,20 @@ int lbh_set_option(lbh_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "bq_mode")) c->bq_mode = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else if (!strcmp(name, "spin_us")) c->spin_us = (int)std::max<int64_t>(0, std::min<int64_t>(1000000, value));
     else return fail(LBH_E_INVALID, "unknown option %s", name);
+    return LBH_OK;
+}
+
+int lbh_host_alloc(lbh_ctx* c, int64_t bytes, void** out_ptr) {
+    if (!c || !out_ptr || bytes < 0) return fail(LBH_E_INVALID, "bad argument");
+    *out_ptr = nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipHostMalloc(out_ptr, (size_t)std::max<int64_t>(bytes, 1), hipHostMallocDefault));
+    return LBH_OK;
+}
+
+int lbh_host_free(lbh_ctx* c, void* ptr) {
+    if (!c) return fail(LBH_E_INVALID, "bad argument");
+    if (ptr) HIP_TRY(hipHostFree(ptr));
     return LBH_OK;
 }
 
@@ -625,51 +649,60 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
         if (rc) return rc;
     }
     const int64_t r0 = ix->n;
-    // per-claim metadata: created_ms | tagmask | keys (as 4 big-endian-decoded words)
-    int rc = ensure_staging(ix, n * (8 + 8 + 32));
-    if (rc) return rc;
-    int64_t* h_created = reinterpret_cast<int64_t*>(ix->staging);
-    uint64_t* h_tags = reinterpret_cast<uint64_t*>(h_created + n);
-    uint64_t* h_keys = h_tags + n;
-    memcpy(h_created, created_ms, (size_t)n * 8);
-    if (tagmask) memcpy(h_tags, tagmask, (size_t)n * 8);
-    else memset(h_tags, 0, (size_t)n * 8);
-    for (int64_t i = 0; i < n * 4; ++i) h_keys[i] = load_be64(hashkey + 8 * i);
-    HIP_TRY(hipMemcpyAsync(ix->created + r0, h_created, (size_t)n * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ix->tags + r0, h_tags, (size_t)n * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ix->keys + r0 * 4, h_keys, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    // Per-claim metadata goes straight from the caller's arrays to their device columns (asynchronous DMA when the
+    // arrays are pinned -- lbh_host_alloc -- else the runtime stages them); the 32 key bytes are decoded into their four
+    // big-endian words by a kernel, not by a host loop.
+    HIP_TRY(hipMemcpyAsync(ix->created + r0, created_ms, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    if (tagmask) HIP_TRY(hipMemcpyAsync(ix->tags + r0, tagmask, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    else HIP_TRY(hipMemsetAsync(ix->tags + r0, 0, (size_t)n * 8, s));
+    HIP_TRY(hipMemcpyAsync(ix->keys + r0 * 4, hashkey, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(lbh_launch_bswap_u64(ix->keys + r0 * 4, n * 4, s));
     HIP_TRY(lbh_launch_iota_u64(ix->order + r0, (uint64_t)ix->row_of_id.size(), n, s));
     HIP_TRY(lbh_launch_iota_u64(ix->ids + r0, (uint64_t)ix->row_of_id.size(), n, s));
     double batch_norm = 1.0;  // K1 writes unit vectors (or zero)
+    std::vector<int64_t> rel;  // must outlive the copies below: freed after the final synchronise
     if (emb_f64) {
         batch_norm = 0.0;
         for (int64_t i = 0; i < n; ++i) batch_norm = std::max(batch_norm, vec_norm(emb_f64 + i * 64));
-        if (!(batch_norm <= 1e15)) return fail(LBH_E_INVALID, "a vector is not finite (or its norm exceeds 1e15)");
+        if (!(batch_norm <= 1e15)) {
+            (void)hipStreamSynchronize(s);
+            return fail(LBH_E_INVALID, "a vector is not finite (or its norm exceeds 1e15)");
+        }
         HIP_TRY(hipMemcpyAsync(ix->emb64 + r0 * 64, emb_f64, (size_t)n * 512, hipMemcpyHostToDevice, s));
         HIP_TRY(lbh_launch_f64_to_f32(ix->emb64 + r0 * 64, ix->emb32 + r0 * 64, n * 64, s));
     } else {
         const int64_t base = offsets[0], bytes = offsets[n] - base;
-        if (bytes < 0 || (bytes > 0 && !utf8)) return fail(LBH_E_INVALID, "bad offsets");
-        for (int64_t i = 0; i < n; ++i) {
+        bool bad = bytes < 0 || (bytes > 0 && !utf8);
+        for (int64_t i = 0; i < n && !bad; ++i) {
             const int64_t l = offsets[i + 1] - offsets[i];
-            if (l < 0 || l >= (int64_t)0x7FFFFF00) return fail(LBH_E_INVALID, "text %lld has invalid length", (long long)i);
+            bad = l < 0 || l >= (int64_t)0x7FFFFF00;
+        }
+        if (bad) {
+            (void)hipStreamSynchronize(s);
+            return fail(LBH_E_INVALID, "bad offsets (a text has a negative length or 2 GiB and more)");
         }
         std::lock_guard<std::mutex> lk2(c->mu);
-        rc = ensure_ctx_scratch(c, bytes + 64, n + 1, 0);
+        const int rc = ensure_ctx_scratch(c, bytes + 64, n + 1, 0);
         if (rc) return rc;
-        std::vector<int64_t> rel;
         const int64_t* offp = offsets;
         if (base != 0) {
             rel.resize((size_t)n + 1);
             for (int64_t i = 0; i <= n; ++i) rel[(size_t)i] = offsets[i] - base;
             offp = rel.data();
         }
-        if (bytes > 0) HIP_TRY(hipMemcpyAsync(c->d_text, utf8 + base, (size_t)bytes, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(c->d_off, offp, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
-        HIP_TRY(lbh_launch_embed(c->d_text, c->d_off, n, ix->emb64 + r0 * 64, ix->emb32 + r0 * 64, s));
-        HIP_TRY(hipStreamSynchronize(s));  // rel / caller buffers may go away
+        // The batch is cut into slices: slice i + 1's text and offsets cross PCIe on the copy stream while K1 vectorises
+        // slice i on the compute stream (offsets stay absolute into the one text blob, so a slice is just a pointer pair).
+        const int n_sl = (int)std::max<int64_t>(1, std::min<int64_t>(LBH_ADD_SLICES, n / 65536));
+        for (int sl = 0; sl < n_sl; ++sl) {
+            const int64_t a = n * sl / n_sl, b2 = n * (sl + 1) / n_sl;
+            const int64_t t0 = offp[a], t1 = offp[b2];
+            if (t1 > t0) HIP_TRY(hipMemcpyAsync(c->d_text + t0, utf8 + base + t0, (size_t)(t1 - t0), hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(hipMemcpyAsync(c->d_off + a, offp + a, (size_t)(b2 - a + 1) * 8, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(hipEventRecord(c->copy_ev[sl], c->copy_stream));
+            HIP_TRY(hipStreamWaitEvent(s, c->copy_ev[sl], 0));
+            HIP_TRY(lbh_launch_embed(c->d_text, c->d_off + a, b2 - a, ix->emb64 + (r0 + a) * 64, ix->emb32 + (r0 + a) * 64, s));
+        }
     }
-    HIP_TRY(hipStreamSynchronize(s));
     const uint64_t id0 = (uint64_t)ix->row_of_id.size();
     ix->row_of_id.resize(ix->row_of_id.size() + (size_t)n);
     ix->id_of_row.resize((size_t)(r0 + n));
@@ -680,6 +713,15 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
     }
     ix->n += n;
     ix->max_norm = std::max(ix->max_norm, batch_norm);
+    // ONE synchronisation per call, after the host-side id maps were brought up to date under the GPU's work: the
+    // caller's buffers (and `rel`) are free again when this returns
+    const hipError_t e_sync = hipStreamSynchronize(s);
+    if (e_sync != hipSuccess) {  // the rows are not usable: take them back
+        ix->n -= n;
+        ix->row_of_id.resize((size_t)id0);
+        ix->id_of_row.resize((size_t)r0);
+        return fail(LBH_E_DEVICE, "lbh_index_add: %s", hipGetErrorString(e_sync));
+    }
     return LBH_OK;
 }
 

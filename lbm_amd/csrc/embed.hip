@@ -391,6 +391,12 @@ __global__ void iota_u64_kernel(uint64_t* dst, uint64_t first, int64_t n) {
     if (i < n) dst[i] = first + (uint64_t)i;
 }
 
+// in place: the 32 key bytes of a claim as uploaded -> their four big-endian words (word 0 most significant)
+__global__ void bswap_u64_kernel(uint64_t* p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = __builtin_bswap64(p[i]);
+}
+
 // dst[rows[i]] = vals[i]  (rows are distinct: one claim id maps to one row)
 __global__ void scatter_u64_kernel(uint64_t* dst, const int64_t* __restrict__ rows, const uint64_t* __restrict__ vals, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -445,6 +451,14 @@ hipError_t lbh_launch_f64_to_f16_tiled(const double* emb64_dev, uint16_t* emb16_
     int64_t blocks = ((row1 - row0) * 8 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     f64_to_f16_tiled_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(emb64_dev, reinterpret_cast<_Float16*>(emb16_dev), row0, row1);
+    return hipGetLastError();
+}
+
+hipError_t lbh_launch_bswap_u64(uint64_t* p, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    bswap_u64_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(p, n);
     return hipGetLastError();
 }
 

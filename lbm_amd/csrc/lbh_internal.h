@@ -160,6 +160,7 @@ hipError_t lbh_launch_move_rows(float* emb32, double* emb64, uint16_t* emb16, in
 hipError_t lbh_launch_gather_rows_f64(const double* emb64, const int64_t* rows_dev, int64_t n, double* out_dev, hipStream_t s);
 hipError_t lbh_launch_f64_to_f16_tiled(const double* emb64_dev, uint16_t* emb16_dev, int64_t row0, int64_t row1, hipStream_t s);
 hipError_t lbh_launch_iota_u64(uint64_t* dst, uint64_t first, int64_t n, hipStream_t s);
+hipError_t lbh_launch_bswap_u64(uint64_t* p, int64_t n, hipStream_t s);
 hipError_t lbh_launch_scatter_u64(uint64_t* dst, const int64_t* rows_dev, const uint64_t* vals_dev, int64_t n, hipStream_t s);
 // search.hip
 int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu);

@@ -383,3 +383,34 @@ def test_group_graph_save_load_and_rebuild(hip, tmp_path, golden_snapshot):
     assert node.groups["g1"].graph is not old
     for q in ("beta", "gamma delta", ""):
         assert node.compile_context("g1", q, top_k=10) == og.compile(q, top_k=10)
+
+
+def test_ingest_from_pinned_buffers_equals_pageable(hip):
+    """lbh_host_alloc + lbh_index_add: the sliced, overlapped upload (pinned arrays, several slices per call, keys decoded
+    on the device, one synchronisation) must leave exactly the rows the plain path leaves -- embeddings against the
+    oracle, and identical search answers; offsets that do not start at 0 and batches below one slice included."""
+    from lbm_amd import synth
+    ch = synth.make_chunk(0, 300_000, seed=4, real_sha_keys=False)
+    a, b = hip.Index(), hip.Index()
+    pins = [hip.pinned_like(x) for x in (ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)]
+    ids = a.add_texts(*(p.a for p in pins))
+    assert ids.tolist() == list(range(ch.n))
+    # the same claims in three calls of different sizes, the later ones with offsets that start inside the blob
+    for lo, hi in ((0, 1000), (1000, 200_000), (200_000, ch.n)):
+        b.add_texts(ch.blob, ch.offsets[lo: hi + 1], ch.created_ms[lo:hi], ch.tagmask[lo:hi], ch.keys[lo:hi])
+    rng = np.random.default_rng(0)
+    pick = rng.choice(ch.n, size=3000, replace=False)
+    want = orc.embed_batch([ch.text(int(i)) for i in pick])
+    assert a.get_embeddings(ids[pick]).tobytes() == want.tobytes()
+    assert b.get_embeddings(ids[pick]).tobytes() == want.tobytes()
+    qv = hip.embed_batch(synth.make_queries(6, seed=8) + [""])
+    for q in qv:
+        for k, since, tm in ((8, hip.SINCE_NONE, 0), (64, int(ch.created_ms[150_000]), 0xFF)):
+            ra, rb = a.search_shard(q, k, since, tm), b.search_shard(q, k, since, tm)
+            assert ra[0].tolist() == rb[0].tolist() and ra[1].tobytes() == rb[1].tobytes() and ra[2].tobytes() == rb[2].tobytes()
+    # the ordering keys are the raw key bytes: ties on an all-zero query come back in ascending key order
+    ia, _, ka = a.search_shard(np.zeros(64), 32)
+    assert [bytes(k) for k in ka] == sorted(bytes(k) for k in ka) and [bytes(ch.keys[i]) for i in ia.tolist()] == [bytes(k) for k in ka]
+    for p in pins:
+        p.close()
+    a.close(); b.close()
