@@ -180,7 +180,7 @@ int lbh_index_search_shard(lbh_index* idx, const double* q_f64, int64_t k, int64
  * (larger values are rejected, not paged).  The query travels as a kernel argument; the call enqueues its kernels on
  * the context's stream and returns after one hipStreamSynchronize.  Calls on one GPU share that GPU's array: they are
  * serialised per context, and two contexts (or processes' threads) on the same GPU must not overlap such calls. */
-#define LBH_NOALLOC_SCRATCH_BYTES 1445120
+#define LBH_NOALLOC_SCRATCH_BYTES 1445376
 #define LBH_NOALLOC_MAX_ROWS 4294967280LL
 int lbh_search_dev_noalloc(lbh_ctx* ctx, const float* emb32_dev, const double* emb64_dev, const int64_t* created_ms_dev,
                            const uint64_t* tagmask_dev, const uint64_t* keywords_dev, int64_t n, double max_row_norm,

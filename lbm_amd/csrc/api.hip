@@ -579,11 +579,11 @@ int index_alloc_workspace(lbh_index* ix) {
     HIP_TRY(hipMalloc((void**)&w.cand, (size_t)LBH_MAX_BLOCKS * LBH_LIST_CAP * 8));
     HIP_TRY(hipMalloc((void**)&w.xcand_ord, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 8));
     HIP_TRY(hipMalloc((void**)&w.xcand_row, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 4));
-    HIP_TRY(hipMalloc((void**)&w.flags, 256));
+    HIP_TRY(hipMalloc((void**)&w.flags, 512));
     HIP_TRY(hipHostMalloc((void**)&w.result_host, sizeof(lbh_result), hipHostMallocMapped | hipHostMallocCoherent));
     HIP_TRY(hipHostGetDevicePointer((void**)&w.result_dev, w.result_host, 0));
     memset(w.result_host, 0, sizeof(lbh_result));
-    HIP_TRY(hipMemset(w.flags, 0, 256));
+    HIP_TRY(hipMemset(w.flags, 0, 512));
     for (auto& ev : ix->ev) HIP_TRY(hipEventCreate(&ev));
     return LBH_OK;
 }

@@ -126,7 +126,7 @@ struct lbh_workspace {
     uint64_t* cand;           // flat, LBH_MAX_BLOCKS x LBH_LIST_CAP entries (ord32<<32 | row)   fast path
     uint64_t* xcand_ord;      // flat, LBH_MAX_BLOCKS*4 x LBH_MAX_PAGE entries: ord64(score)     exact path
     uint32_t* xcand_row;      // same shape: row
-    int32_t* flags;           // [0] overflow, [1] entries in cand, [2] entries in xcand (zeroed per launch)
+    int32_t* flags;           // 128 ints: [0] overflow, [1] entries in cand, [2] entries in xcand, [64..127] the scan blocks' shared cuts (zeroed by the select kernels)
     // batched (K3) workspace, allocated on first use
     double* bq_qmat;          // 256 x 64 fp64 query matrix
     uint64_t* bq_cand;        // 256 x LBH_BQ_PERQ flat candidate lists, one per query

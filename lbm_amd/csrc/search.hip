@@ -52,6 +52,64 @@ __device__ __forceinline__ void sort_desc_u64(uint64_t* buf, int n, int tid, int
     }
 }
 
+// The same sort for ONE wave, in registers: entry i = r * 64 + lane sits in register r of its lane, the compare-exchange
+// partner of a step with distance j is another register of the same lane (j >= 64) or the same register of lane ^ j (two
+// 32-bit cross-lane moves).  The LDS version above spends ~500 cycles per step on dependent LDS round trips and wave
+// barriers (5 us for 64-128 entries, measured with the K2 block timeline); this one is ~20 instructions per step.
+// buf[0 .. 64 R) must be readable; entries at and beyond `cnt` are taken as 0 (they sort last).
+template <int R>
+__device__ __forceinline__ void wave_sort_desc_u64(uint64_t* buf, int cnt, int lane) {
+    uint64_t v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = (r * 64 + lane) < cnt ? buf[r * 64 + lane] : 0ull;
+#pragma unroll
+    for (int k = 2; k <= 64 * R; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                constexpr int dummy = 0; (void)dummy;
+                const int jr = j >> 6;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if ((r & jr) == 0) {  // r and r | jr are partners; the lower index keeps the larger value when descending
+                        const int i = r * 64 + lane;
+                        const bool desc = (i & k) == 0;
+                        const uint64_t a = v[r], b = v[r | jr];
+                        const bool sw = desc ? (a < b) : (a > b);
+                        v[r] = sw ? b : a;
+                        v[r | jr] = sw ? a : b;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int i = r * 64 + lane;
+                    const bool desc = (i & k) == 0;
+                    const bool lower = (lane & j) == 0;  // this lane holds the lower index of the pair
+                    const uint64_t mine = v[r];
+                    const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)mine, j);
+                    const uint32_t ohi = (uint32_t)__shfl_xor((int)(uint32_t)(mine >> 32), j);
+                    const uint64_t other = ((uint64_t)ohi << 32) | olo;
+                    // the lower index keeps max when descending, min when ascending; the upper index the opposite
+                    const bool want_max = desc == lower;
+                    v[r] = want_max ? (mine > other ? mine : other) : (mine < other ? mine : other);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < R; ++r) buf[r * 64 + lane] = v[r];
+    __builtin_amdgcn_wave_barrier();
+}
+
+// n2 (a power of two, 64 .. 256) entries of buf, of which the first cnt are real
+__device__ __forceinline__ void wave_sort_desc_dispatch(uint64_t* buf, int cnt, int n2, int lane) {
+    if (n2 <= 64) wave_sort_desc_u64<1>(buf, cnt, lane);
+    else if (n2 <= 128) wave_sort_desc_u64<2>(buf, cnt, lane);
+    else wave_sort_desc_u64<4>(buf, cnt, lane);
+}
+
 // hash-key comparison: true when key(ra) < key(rb) (big-endian integer order of the 32 key bytes)
 __device__ __forceinline__ bool key_less(const uint64_t* __restrict__ keys, uint32_t ra, uint32_t rb) {
     const uint64_t* a = keys + (size_t)ra * 4;
@@ -139,6 +197,12 @@ __device__ __forceinline__ double exact_dot_latency(const double* __restrict__ q
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 
+#ifdef LBH_K2_TIMING  // instrumented build (tools/scripts/k2_phases.py): 100 MHz wall-clock stamps of every block's first wave
+__device__ long long lbh_k2_dbg[LBH_MAX_BLOCKS][6];
+#define K2_STAMP(i) do { if (threadIdx.x == 0) lbh_k2_dbg[blockIdx.x][i] = wall_clock64(); } while (0)
+#else
+#define K2_STAMP(i)
+#endif
 template <bool SINCE, bool TAGS, bool NT, bool HALF>
 __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_index ix, const uint16_t* __restrict__ emb16,
                                                                      const double* __restrict__ qptr, lbh_qarg qa,
@@ -173,6 +237,7 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
     const int64_t n_vec = n * 16;  // 16-byte chunks in the fp32 matrix (the fp16 copy is padded to whole 64-row steps)
     uint64_t* buf = wbuf[wave];
 
+    K2_STAMP(0);
     uint32_t thr = 0;  // ordered image of (k-th best so far - margin); 0 admits everything
     // first compaction as soon as a threshold can exist (keeps the warm-up short on small corpora)
     int trigger = 4 * k < 64 ? 64 : (4 * k > LBH_WCAP - 64 ? LBH_WCAP - 64 : 4 * k);
@@ -182,9 +247,8 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
     // sort the wave buffer, raise the threshold, drop what fell below it
     auto compact = [&]() {
         const int n2 = pow2_at_least(cnt, 64);
-        for (int i = cnt + lane; i < n2; i += 64) buf[i] = 0;
         __builtin_amdgcn_wave_barrier();
-        sort_desc_u64(buf, n2, lane, 64, WaveSync());
+        wave_sort_desc_dispatch(buf, cnt, n2, lane);  // in registers; slots [cnt, n2) come back as 0
         if (cnt >= k) {
             const uint32_t kth = (uint32_t)(buf[k - 1] >> 32);
             const uint32_t nt = lbh_ord32(lbh_unord32(kth) - margin);
@@ -286,9 +350,12 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
             }
         }
     }
+    K2_STAMP(1);
     if (!dead && cnt > 0) compact();
+    K2_STAMP(2);
     if (lane == 0) wcnt[wave] = cnt;
     __syncthreads();
+    K2_STAMP(3);
 
     // block merge: concatenate the wave lists, sort, keep everything within the margin of the block's k-th
     int off = 0, total = 0;
@@ -302,13 +369,65 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
     for (int i = total + threadIdx.x; i < n2; i += LBH_SCAN_THREADS) mbuf[i] = 0;
     __syncthreads();
     if (total == 0) return;
+    // A block's k-th best score is a lower bound of the corpus's, so (k-th - margin) of ANY block may cut every block's
+    // output.  flags[64..127] are 64 slots of such cuts (ordered images; zeroed by the select kernel): a block stores
+    // its own cut into slot (block % 64) with a plain device-scope store and applies the largest of the 64 values it then
+    // reads.  Nothing here needs to be exact -- a lost or stale slot is merely a looser, still valid cut -- so there is
+    // no atomic (one shared word raised by atomicMax made every finishing block queue behind all the others: the 1 M-claim
+    // scan went from 56 to 66 us).  Late blocks emit almost nothing, and the select kernel sorts a few hundred entries
+    // instead of radix-selecting among #blocks x k.
+    unsigned int* gslot = reinterpret_cast<unsigned int*>(&flags[64]);
+    // The slots are read FIRST (the load is in flight while the merged list is sorted) and the block's own cut is stored
+    // LAST, with nothing waiting for it: a device-scope 4-byte store takes microseconds to complete, and behind it in the
+    // same wave's memory queue the load of the slots cost every block 5-8 us of its tail.
+    uint32_t gseen = 0;
+    if (wave == 0) gseen = __hip_atomic_load(&gslot[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto shared_cut = [&](uint32_t own) -> uint32_t {  // wave 0 only
+        uint32_t g = gseen;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t t = (uint32_t)__shfl_xor((int)g, o);
+            g = t > g ? t : g;
+        }
+        return g > own ? g : own;
+    };
+    auto publish_cut = [&](uint32_t own) {
+        if (lane == 0) __hip_atomic_store(&gslot[blockIdx.x & 63], own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+#ifndef LBH_SCAN_WAVE_EPI
+#define LBH_SCAN_WAVE_EPI 1
+#endif
+    if (LBH_SCAN_WAVE_EPI && total <= 128) {
+        // the usual case (each wave kept ~k rows): one wave sorts the merged list, no more block barriers
+        if (wave != 0) return;
+        wave_sort_desc_dispatch(mbuf, total, n2, lane);
+        uint32_t own = 0;
+        if (total >= k) own = lbh_ord32(lbh_unord32((uint32_t)(mbuf[k - 1] >> 32)) - margin);
+        const uint32_t bthr = shared_cut(own);
+        int ns = 0;  // survivors are a prefix of the sorted list
+        for (int i = lane; i < n2; i += 64) ns += __popcll(__ballot(i < total && (uint32_t)(mbuf[i] >> 32) >= bthr));
+        K2_STAMP(4);
+        int base = 0;
+        if (lane == 0 && ns > 0) base = atomicAdd(&flags[1], ns);
+        base = __shfl(base, 0);
+        for (int i = lane; i < ns; i += 64) cand[base + i] = mbuf[i];
+        if (total >= k) publish_cut(own);
+        K2_STAMP(5);
+        return;
+    }
     sort_desc_u64(mbuf, n2, threadIdx.x, LBH_SCAN_THREADS, BlockSync());
     uint32_t bthr = 0;
     if (total >= k) bthr = lbh_ord32(lbh_unord32((uint32_t)(mbuf[k - 1] >> 32)) - margin);
+    const uint32_t own_cut = bthr;
     // survivors are a prefix of the sorted array; they go to one flat candidate array in HBM
     __shared__ int nsurv, gbase;
-    if (threadIdx.x == 0) nsurv = 0;
+    __shared__ uint32_t sh_bthr;
+    if (wave == 0) {
+        const uint32_t c = shared_cut(bthr);
+        if (lane == 0) { nsurv = 0; sh_bthr = c; }
+    }
     __syncthreads();
+    bthr = sh_bthr;  // one value for the whole block
     for (int i = threadIdx.x; i < total; i += LBH_SCAN_THREADS) {
         const bool in = (uint32_t)(mbuf[i] >> 32) >= bthr;
         const bool next_in = (i + 1 < total) && (uint32_t)(mbuf[i + 1] >> 32) >= bthr;
@@ -324,6 +443,7 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
     __syncthreads();
     const int base = gbase;
     for (int i = threadIdx.x; i < ns; i += LBH_SCAN_THREADS) cand[base + i] = mbuf[i];
+    if (wave == 0 && total >= k) publish_cut(own_cut);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -332,6 +452,7 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
 // ------------------------------------------------------------------------------------------------
 constexpr int SEL_THREADS = 1024;
 constexpr int LBH_SORT_ALL = 1024;  // select_fast_body: candidate lists up to this size are sorted whole
+constexpr int LBH_RANK_ALL = 768;   // ... and up to this size the k-th best is found by rank counting, without a sort
 
 template <class F>
 __device__ uint64_t block_radix_select(int E, int nbytes, int64_t krem, F val, int* hist, int64_t* sh_krem,
@@ -459,7 +580,32 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
     __syncthreads();
     int M = 0;
     uint32_t thr = 0;
-    if (E <= LBH_SORT_ALL) {  // few entries: sort them all; more: radix-select the k-th score first (a 4096-entry sort took 20+ us)
+    if (E <= LBH_RANK_ALL) {
+        // A short list (the scan blocks share their cuts, so this is the usual case): no sort at all.  Thread t counts the
+        // entries above entry t (entries are unique: the row sits in the low word; every thread reads the same LDS word at
+        // the same time, a broadcast) -- the one with k - 1 above it is the k-th best.  Four barriers instead of the
+        // bitonic sort's 36-45.
+        __shared__ uint32_t sh_thr;
+        uint64_t v = 0;
+        if (tid < E) v = cand[tid];
+        if (tid < E) sbuf[tid] = v;
+        if (tid == 0) sh_thr = 0;
+        __syncthreads();
+        if (E >= k && tid < E) {
+            int above = 0;
+            for (int i = 0; i < E; ++i) above += sbuf[i] > v;
+            if (above == k - 1) sh_thr = lbh_ord32(lbh_unord32((uint32_t)(v >> 32)) - margin);
+        }
+        __syncthreads();
+        thr = sh_thr;
+        const bool keep = tid < E && (uint32_t)(v >> 32) >= thr;
+        int pos = 0;
+        if (keep) pos = atomicAdd(&sh_cnt, 1);
+        __syncthreads();  // every entry is in a register before the survivors are packed into sbuf
+        if (keep) sbuf[pos] = v;
+        __syncthreads();
+        M = sh_cnt;
+    } else if (E <= LBH_SORT_ALL) {  // few entries: sort them all; more: radix-select the k-th score first (a 4096-entry sort took 20+ us)
         for (int e = tid; e < E; e += SEL_THREADS) sbuf[e] = cand[e];
         const int n2 = pow2_at_least(E, 2);
         for (int i = E + tid; i < n2; i += SEL_THREADS) sbuf[i] = 0;
@@ -541,7 +687,7 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
 // has fenced to system scope thread 0 publishes the caller's sequence number and the host may read the
 // block as soon as it sees that number (no stream synchronisation on the latency path).
 __device__ __forceinline__ void publish_result(lbh_result* res, int seq) {
-    __threadfence_system();
+    if (threadIdx.x < 64) __threadfence_system();  // the result block is written by threads 0..63 only (<= LBH_MAX_PAGE rows + the header)
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&res->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -559,6 +705,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index 
     if (tid < 64) qs[tid] = qptr ? qptr[tid] : qa.q[tid];
     __syncthreads();
     if (tid < 4) flags[tid] = 0;  // leave the counters zeroed for the next launch (no memset node needed)
+    if (tid >= 64 && tid < 128) flags[tid] = 0;  // and the scan blocks' shared cuts
     if (overflowed) {
         if (tid == 0) { res->count = 0; res->overflow = 1; res->candidates = 0; }
     } else {
@@ -1473,6 +1620,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_exact_kernel(lbh_dev_index
     const int E = flags[2];
     __syncthreads();
     if (tid < 4) flags[tid] = 0;
+    if (tid >= 64 && tid < 128) flags[tid] = 0;
     uint64_t* xo = sbuf;
     uint32_t* xr = reinterpret_cast<uint32_t*>(sbuf + LBH_MCAP);
 
@@ -1946,7 +2094,7 @@ constexpr size_t NA_OFF_CAND = 0;
 constexpr size_t NA_OFF_XORD = NA_OFF_CAND + (size_t)NA_FAST_BLOCKS * LBH_LIST_CAP * 8;                        // 1 MiB
 constexpr size_t NA_OFF_XROW = NA_OFF_XORD + (size_t)NA_EXACT_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 8;      // + 256 KiB
 constexpr size_t NA_OFF_FLAGS = NA_OFF_XROW + (size_t)NA_EXACT_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 4;     // + 128 KiB
-constexpr size_t NA_OFF_RESULT = NA_OFF_FLAGS + 256;
+constexpr size_t NA_OFF_RESULT = NA_OFF_FLAGS + 512;
 constexpr size_t NA_BYTES = NA_OFF_RESULT + ((sizeof(lbh_result) + 255) / 256) * 256;
 static_assert(NA_BYTES == LBH_NOALLOC_SCRATCH_BYTES, "include/lbhip.h states the size of the scratch array");
 
@@ -1980,7 +2128,7 @@ hipError_t lbh_launch_search_noalloc(void* scratch_ptr, const lbh_dev_index& ix,
     int32_t* flags = reinterpret_cast<int32_t*>(base + NA_OFF_FLAGS);
     lbh_result* res = reinterpret_cast<lbh_result*>(base + NA_OFF_RESULT);
     // the array keeps the last call's contents: counters and the result header must start at zero
-    hipError_t e = hipMemsetAsync(flags, 0, 256 + 64, s);
+    hipError_t e = hipMemsetAsync(flags, 0, 512 + 64, s);
     if (e != hipSuccess) return e;
     int grid = lbh_scan_grid(ix.n, n_cu, 2);
     if (grid > NA_FAST_BLOCKS) grid = NA_FAST_BLOCKS;
@@ -2149,6 +2297,11 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* em
     return hipGetLastError();
 }
 
+#ifdef LBH_K2_TIMING
+extern "C" int lbh_debug_k2_times(long long* out) {  // instrumented build only: LBH_MAX_BLOCKS x 6 stamps
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lbh_k2_dbg), sizeof(long long) * LBH_MAX_BLOCKS * 6);
+}
+#endif
 #if LBH_BQ_ABLATE == 10
 extern "C" int lbh_debug_k3_times(long long* out) {  // instrumented build only: 3 x 256 x 5 ticks (tools/scripts/k3_phases.py)
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lbh_k3_dbg), sizeof(long long) * 3 * 256 * 5);

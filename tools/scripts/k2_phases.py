@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Timeline of the single-query scan's blocks (instrumented build of the library, LBH_K2_TIMING in search.hip):
+   make -C lbm_amd/csrc k2timing  ->  abl/liblbhip_k2t.so;   LBM_HIP_LIB=.../liblbhip_k2t.so python3 tools/scripts/k2_phases.py [claims]
+Stamps per block (first wave): 0 start, 1 main loop done, 2 final wave compaction done, 3 block barrier passed, 4 merged list
+sorted + shared cut applied, 5 candidates written."""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from lbm_amd import _hip
+lib = ctypes.CDLL(os.environ["LBM_HIP_LIB"])
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+rng = np.random.default_rng(0)
+ix = _hip.Index()
+for s in range(0, n, 1_000_000):
+    m = min(1_000_000, n - s)
+    v = rng.standard_normal((m, 64)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    ix.add_vectors(v, np.arange(s, s + m, dtype=np.int64), None, rng.integers(0, 256, size=(m, 32), dtype=np.uint8))
+q = rng.standard_normal(64); q /= np.linalg.norm(q)
+st = _hip.Stats(); st.want_timing = 1
+for _ in range(5):
+    ix.search_shard(q, 8, _hip.SINCE_NONE, 0, st)
+out = np.zeros((2048, 6), dtype=np.int64)
+lib.lbh_debug_k2_times(out.ctypes.data_as(ctypes.c_void_p))
+g = min(512, (n + 255) // 256)
+t = out[:g].astype(np.float64) / 100.0  # us
+t0 = t[:, 0].min()
+names = ["start", "loop done", "wave compact", "barrier", "sorted+cut", "written"]
+print(f"claims {n}, blocks {g}, scan event time {st.scan_ms * 1e3:.1f} us")
+for i, nm in enumerate(names):
+    c = t[:, i] - t0
+    print(f"  {nm:14s} first {c.min():7.2f}  median {np.median(c):7.2f}  last {c.max():7.2f} us after the first block's start")
+d = np.diff(t, axis=1)
+print("  per-block phase medians (us):", {names[i + 1]: round(float(np.median(d[:, i])), 2) for i in range(5)})
