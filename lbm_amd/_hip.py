@@ -340,8 +340,7 @@ class Index:
         h = _vp()
         _check(self._L.lbh_index_create(context(), ctypes.byref(h)))
         self._h = h
-        self._shard_bufs = {}
-        self._shard_lock = threading.Lock()  # the cached output buffers of search_shard are per index, not per thread
+        self._tls = threading.local()  # cached output buffers of search_shard / search_sharded: per index AND per thread
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -480,20 +479,28 @@ class Index:
         k = max(0, int(k))
         mul = comm.world if gid_mul is None else int(gid_mul)
         add = comm.rank if gid_add is None else int(gid_add)
-        with self._shard_lock:
-            buf = self._shard_bufs.get(("x", k))
-            if buf is None:
-                kk = max(k, 1)
-                ids = np.zeros(kk, dtype=np.uint64)
-                sc = np.zeros(kk, dtype=np.float64)
-                keys = np.zeros((kk, KEY_BYTES), dtype=np.uint8)
-                cnt = _i64(0)
-                buf = self._shard_bufs[("x", k)] = (ids, sc, keys, cnt, _ptr(ids), _ptr(sc), _ptr(keys), ctypes.byref(cnt))
-            ids, sc, keys, cnt, p_ids, p_sc, p_keys, p_cnt = buf
-            _check(self._L.lbh_index_search_sharded(self._h, comm._h, q.ctypes.data, k, _since(since_ms), int(tag_mask), mul, add,
-                                                    p_ids, p_sc, p_keys, p_cnt, ctypes.byref(stats) if stats is not None else None))
-            n = cnt.value
-            return ids[:n].copy(), sc[:n].copy(), keys[:n].copy()
+        ids, sc, keys, cnt, p_ids, p_sc, p_keys, p_cnt = self._out_bufs(k)
+        _check(self._L.lbh_index_search_sharded(self._h, comm._h, q.ctypes.data, k, _since(since_ms), int(tag_mask), mul, add,
+                                                p_ids, p_sc, p_keys, p_cnt, ctypes.byref(stats) if stats is not None else None))
+        n = cnt.value
+        return ids[:n].copy(), sc[:n].copy(), keys[:n].copy()
+
+    def _out_bufs(self, k: int):
+        """Output arrays and their ctypes pointers, kept per thread and per k (building them costs more than the call)."""
+        bufs = getattr(self._tls, "bufs", None)
+        if bufs is None:
+            bufs = self._tls.bufs = {}
+        buf = bufs.get(k)
+        if buf is None:
+            if len(bufs) > 64:
+                bufs.clear()
+            kk = max(k, 1)
+            ids = np.zeros(kk, dtype=np.uint64)
+            sc = np.zeros(kk, dtype=np.float64)
+            keys = np.zeros((kk, KEY_BYTES), dtype=np.uint8)
+            cnt = _i64(0)
+            buf = bufs[k] = (ids, sc, keys, cnt, _ptr(ids), _ptr(sc), _ptr(keys), ctypes.byref(cnt))
+        return buf
 
     def search_shard(self, q: np.ndarray, k: int, since_ms: int = SINCE_NONE, tag_mask: int = 0,
                      stats: Optional[Stats] = None):
@@ -504,20 +511,9 @@ class Index:
         k = max(0, int(k))
         if k > 4096:  # never allocate for more results than there are claims
             k = min(k, self.size())
-        with self._shard_lock:
-            buf = self._shard_bufs.get(k)
-            if buf is None:
-                if len(self._shard_bufs) > 64:
-                    self._shard_bufs.clear()
-                kk = max(k, 1)
-                ids = np.zeros(kk, dtype=np.uint64)
-                sc = np.zeros(kk, dtype=np.float64)
-                keys = np.zeros((kk, KEY_BYTES), dtype=np.uint8)
-                cnt = _i64(0)
-                buf = self._shard_bufs[k] = (ids, sc, keys, cnt, _ptr(ids), _ptr(sc), _ptr(keys), ctypes.byref(cnt))
-            ids, sc, keys, cnt, p_ids, p_sc, p_keys, p_cnt = buf
-            # the library clamps k to the number of live claims itself
-            _check(self._L.lbh_index_search_shard(self._h, q.ctypes.data, k, _since(since_ms), int(tag_mask), p_ids, p_sc,
-                                                  p_keys, p_cnt, ctypes.byref(stats) if stats is not None else None))
-            n = cnt.value
-            return ids[:n].copy(), sc[:n].copy(), keys[:n].copy()
+        ids, sc, keys, cnt, p_ids, p_sc, p_keys, p_cnt = self._out_bufs(k)
+        # the library clamps k to the number of live claims itself
+        _check(self._L.lbh_index_search_shard(self._h, q.ctypes.data, k, _since(since_ms), int(tag_mask), p_ids, p_sc,
+                                              p_keys, p_cnt, ctypes.byref(stats) if stats is not None else None))
+        n = cnt.value
+        return ids[:n].copy(), sc[:n].copy(), keys[:n].copy()

@@ -348,8 +348,15 @@ class _EmbeddingCacheView:
 class ContextGraph:
     """Truth-maintenance flavored graph (v1) -- GPU-ranked drop-in (lb/context_graph.py:46-148)."""
 
+    # compile() releases the graph lock while its search runs on the device (the index's own reader/writer lock and
+    # per-search slots take over), so queries from several threads overlap like the reference's lock-free
+    # compile_context (lb/node.py:718-734).  SPMD subclasses, whose searches are collectives, turn this off.
+    _overlap_searches = True
+
     def __init__(self) -> None:
         self._lock = threading.RLock()
+        self._cond = threading.Condition(self._lock)
+        self._readers = 0  # searches in flight outside the lock; the id maps and device rows stay put until they are back
         self._dirty: Dict[str, None] = {}      # insertion-ordered set of hashes to reconcile
         self._pending_text: Dict[str, str] = {}  # text captured by add_claim (embedded at next sync)
         self._id_of: Dict[str, int] = {}       # hash -> device claim id (rows the GPU scans)
@@ -438,6 +445,8 @@ class ContextGraph:
 
     @_locked
     def _drop_row(self, h: str, park: bool) -> None:
+        while self._readers:  # called under the lock; see _sync
+            self._cond.wait()
         cid = self._id_of.pop(h, None)
         if cid is None:
             return
@@ -455,6 +464,10 @@ class ContextGraph:
         kernel), every new text in ONE K1 launch.  Bookkeeping is committed only after the device call it describes has
         succeeded; if a call fails, every hash of the batch is dirty again and parked vectors / pending texts are still
         in place, so a later ``compile`` retries instead of silently missing claims."""
+        if not self._dirty and not self._keys_stale:
+            return
+        while self._readers:  # searches running outside the lock map their ids through _hash_of when they return
+            self._cond.wait()
         if not self._dirty:
             if self._keys_stale:
                 self._refresh_rank_keys()
@@ -653,15 +666,27 @@ class ContextGraph:
                 return since, 0, True  # no claim carries any of the requested tags
         return since, tag_mask, False
 
-    @_locked
     def _rank(self, query, top_k, since_ms, tags, stats=None) -> Tuple[List[str], List[float]]:
-        self._sync()
-        k = max(0, int(top_k))  # :121
-        since, tag_mask, empty = self._filters(since_ms, tags)
-        if empty:
-            return [], []
-        index = self._index  # opens the HIP backend even for an empty graph: no silent CPU path
-        return self._search_text(index, query, k, since, tag_mask, stats)
+        with self._lock:
+            self._sync()
+            k = max(0, int(top_k))  # :121
+            since, tag_mask, empty = self._filters(since_ms, tags)
+            if empty:
+                return [], []
+            index = self._index  # opens the HIP backend even for an empty graph: no silent CPU path
+            if not self._overlap_searches:
+                return self._search_text(index, query, k, since, tag_mask, stats)
+            if k == 0 or not self._id_of:
+                return [], []
+            self._readers += 1
+        try:  # the device part runs without the graph lock: another thread's compile() may overlap it
+            ids, scores, _ = index.search_text(query, k, since, tag_mask, stats)
+            with self._lock:
+                return [self._hash_of[i] for i in ids.tolist()], scores.tolist()
+        finally:
+            with self._cond:
+                self._readers -= 1
+                self._cond.notify_all()
 
     def _search_text(self, index, query: str, k: int, since: int, tag_mask: int, stats) -> Tuple[List[str], List[float]]:
         """Device part of ``compile``: embed(query) + scan + exact top-k -> (hashes, fp64 scores)."""

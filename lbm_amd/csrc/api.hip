@@ -9,7 +9,9 @@
 #include <cstring>
 #include <chrono>
 #include <dlfcn.h>
+#include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -67,9 +69,36 @@ struct lbh_ctx {
     int64_t d_vec_cap = 0;
 };
 
+#define LBH_SLOTS 2  // searches that may run on one index at the same time (each has its own workspace and stream)
+
+// Everything ONE search in flight needs besides the index's arrays: workspace, result block, query, events, stream.
+struct lbh_slot {
+    lbh_workspace ws{};
+    lbh_qarg qarg{};              // current query when it came from the host (kernel argument)
+    const double* qptr = nullptr;  // current query when it was embedded on the GPU (ws.q64), else NULL
+    double qnorm = 1.0;           // |q| of the current query (1 for a query embedded from text)
+    int32_t seq = 0;              // completion ticket of the last single-query launch
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t stream = nullptr;  // slot 0: the context's stream; further slots: their own
+    bool own_stream = false;
+    void* staging = nullptr;      // pinned host staging of the query text
+    int64_t staging_cap = 0;
+    uint8_t* d_text = nullptr;    // query text on the device (search_text)
+    int64_t d_text_cap = 0;
+    int64_t* d_off = nullptr;     // its two offsets
+    uint64_t seen_gen = 0;        // last mutation this slot's own stream was ordered behind (lbh_index::mut_gen)
+    bool busy = false;
+};
+
 struct lbh_index {
     lbh_ctx* ctx = nullptr;
-    std::mutex mu;
+    // Readers and writers (the reference's compile_context takes no lock while publishers hold BatteryNode._lock,
+    // lb/node.py:718 vs :450): searches hold `rw` shared and each leases one slot, so up to LBH_SLOTS of them overlap on
+    // one index; add / retract / metadata edits hold it exclusively and leave their stream drained before they release it.
+    std::shared_mutex rw;
+    std::mutex slot_mu;
+    std::condition_variable slot_cv;
+    lbh_slot* slots[LBH_SLOTS] = {};
     int64_t n = 0, cap = 0;
     float* emb32 = nullptr;
     double* emb64 = nullptr;
@@ -78,21 +107,17 @@ struct lbh_index {
     uint64_t* keys = nullptr;
     uint64_t* order = nullptr;    // per-row insertion-order key of the recency query (defaults to the claim id)
     uint64_t* ids = nullptr;      // per-row claim id (device mirror of id_of_row: the sharded search emits global ids on the GPU)
-    uint16_t* emb16 = nullptr;    // n x 64 fp16 (128 B rows), built on first use of scan_mode 1; rows [0, emb16_rows) are valid
+    uint16_t* emb16 = nullptr;    // fp16 copy in MFMA-fragment order (lbh_emb16_off), built on first use; rows [0, emb16_rows) are valid
     int64_t emb16_rows = 0, emb16_cap = 0;
     std::vector<uint64_t> id_of_row;
     std::vector<int64_t> row_of_id;
-    lbh_workspace ws{};
-    lbh_qarg qarg{};              // current query when it came from the host (kernel argument)
-    const double* qptr = nullptr;  // current query when it was embedded on the GPU (ws.q64), else NULL
     double max_norm = 0.0;    // largest |x| ever added: the scans' error bounds (hence their candidate margins) scale with it
-    double qnorm = 1.0;       // |q| of the current query (1 for a query embedded from text)
-    int32_t seq = 0;          // completion ticket of the last single-query launch
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // per index: searches on two indexes may run concurrently
-    void* staging = nullptr;  // pinned host staging
+    void* staging = nullptr;  // pinned host staging of the mutators (held under the exclusive lock)
     int64_t staging_cap = 0;
     void* dscratch = nullptr;  // device scratch of the batched mutators (row lists, pairs, gathered rows); grow-only
     int64_t dscratch_cap = 0;
+    hipEvent_t mut_ev = nullptr;  // recorded on the context's stream by every mutator: a slot with a stream of its own waits on it
+    uint64_t mut_gen = 0;
 };
 
 namespace {
@@ -177,6 +202,174 @@ int ensure_dscratch(lbh_index* ix, int64_t bytes) {
     return LBH_OK;
 }
 
+// ---- slots and locks -------------------------------------------------------------------------------------------
+constexpr int LBH_NEED_EMB16 = -1000;  // internal: a search found the fp16 copy out of date; rebuilt under the exclusive lock, then retried
+
+int slot_create(lbh_index* ix, int which, lbh_slot** out) {
+    lbh_slot* sl = new (std::nothrow) lbh_slot();
+    if (!sl) return fail(LBH_E_NOMEM, "out of host memory");
+    *out = sl;  // the caller destroys it on failure
+    if (which == 0) sl->stream = ix->ctx->stream;
+    else {
+        HIP_TRY(hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking));
+        sl->own_stream = true;
+    }
+    lbh_workspace& w = sl->ws;
+    HIP_TRY(hipMalloc((void**)&w.q64, 512));
+    HIP_TRY(hipMalloc((void**)&w.cand, (size_t)LBH_MAX_BLOCKS * LBH_LIST_CAP * 8));
+    HIP_TRY(hipMalloc((void**)&w.xcand_ord, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 8));
+    HIP_TRY(hipMalloc((void**)&w.xcand_row, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 4));
+    HIP_TRY(hipMalloc((void**)&w.flags, 512));
+    HIP_TRY(hipMalloc((void**)&sl->d_off, 16));
+    HIP_TRY(hipHostMalloc((void**)&w.result_host, sizeof(lbh_result), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(hipHostGetDevicePointer((void**)&w.result_dev, w.result_host, 0));
+    memset(w.result_host, 0, sizeof(lbh_result));
+    HIP_TRY(hipMemset(w.flags, 0, 512));
+    for (auto& ev : sl->ev) HIP_TRY(hipEventCreate(&ev));
+    return LBH_OK;
+}
+
+void slot_destroy(lbh_slot* sl) {
+    if (!sl) return;
+    if (sl->stream) (void)hipStreamSynchronize(sl->stream);
+    lbh_workspace& w = sl->ws;
+    void* dev[] = {w.rc_a, w.rc_b, w.rc_row, w.rc_cnt, w.q64, w.cand, w.xcand_ord, w.xcand_row, w.flags,
+                   w.bq_qmat, w.bq_cand, w.bq_total, w.bq_seed, w.bq_bfrag, sl->d_text, sl->d_off};
+    for (void* p : dev)
+        if (p) (void)hipFree(p);
+    for (auto& ev : sl->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (w.result_host) (void)hipHostFree(w.result_host);
+    if (w.bq_result_host) (void)hipHostFree(w.bq_result_host);
+    if (w.rc_result_host) (void)hipHostFree(w.rc_result_host);
+    if (sl->staging) (void)hipHostFree(sl->staging);
+    if (sl->own_stream && sl->stream) (void)hipStreamDestroy(sl->stream);
+    delete sl;
+}
+
+// query text of lbh_index_search_text: pinned staging + device copy, per slot (two searches in flight must not share them)
+int slot_text_buffers(lbh_slot* sl, int64_t bytes) {
+    if (bytes > sl->staging_cap) {
+        if (sl->staging) (void)hipHostFree(sl->staging);
+        sl->staging = nullptr;
+        sl->staging_cap = 0;
+        const int64_t cap = std::max<int64_t>(bytes, 1 << 16);
+        HIP_TRY(hipHostMalloc(&sl->staging, (size_t)cap, hipHostMallocDefault));
+        sl->staging_cap = cap;
+    }
+    if (bytes > sl->d_text_cap) {
+        if (sl->d_text) (void)hipFree(sl->d_text);
+        sl->d_text = nullptr;
+        sl->d_text_cap = 0;
+        const int64_t cap = std::max<int64_t>(bytes, 1 << 16);
+        HIP_TRY(hipMalloc((void**)&sl->d_text, (size_t)cap));
+        sl->d_text_cap = cap;
+    }
+    return LBH_OK;
+}
+
+// A reader's hold on the index: the shared side of `rw` plus one slot.  Slot 0 exists from lbh_index_create; the others
+// are made the first time two searches overlap (their workspaces cost device memory only then).
+class Lease {
+  public:
+    explicit Lease(lbh_index* ix) : ix_(ix), lk_(ix->rw) {}
+    Lease(const Lease&) = delete;
+    Lease& operator=(const Lease&) = delete;
+    ~Lease() {
+        if (!sl_) return;
+        {
+            std::lock_guard<std::mutex> g(ix_->slot_mu);
+            sl_->busy = false;
+        }
+        ix_->slot_cv.notify_one();
+    }
+    int acquire() {
+        std::unique_lock<std::mutex> g(ix_->slot_mu);
+        for (;;) {
+            int vacant = -1;
+            for (int i = 0; i < LBH_SLOTS; ++i) {
+                lbh_slot* sl = ix_->slots[i];
+                if (sl && !sl->busy) {
+                    sl->busy = true;
+                    sl_ = sl;
+                    break;
+                }
+                if (!sl && vacant < 0) vacant = i;
+            }
+            if (sl_) break;
+            if (vacant >= 0) {
+                lbh_slot* sl = nullptr;
+                const int rc = slot_create(ix_, vacant, &sl);
+                if (rc) {
+                    slot_destroy(sl);
+                    return rc;
+                }
+                sl->busy = true;
+                ix_->slots[vacant] = sl_ = sl;
+                break;
+            }
+            ix_->slot_cv.wait(g);
+        }
+        g.unlock();
+        // a slot with a stream of its own runs behind the last mutation (mutators work on the context's stream)
+        if (sl_->own_stream && sl_->seen_gen != ix_->mut_gen) {
+            HIP_TRY(hipStreamWaitEvent(sl_->stream, ix_->mut_ev, 0));
+            sl_->seen_gen = ix_->mut_gen;
+        }
+        return LBH_OK;
+    }
+    lbh_slot* slot() const { return sl_; }
+
+  private:
+    lbh_index* ix_;
+    std::shared_lock<std::shared_mutex> lk_;
+    lbh_slot* sl_ = nullptr;
+};
+
+// every mutator (and the bulk readers that borrow the index's own staging) ends with this, still under the exclusive
+// lock: searches on a slot with a stream of its own order themselves behind the event
+int mutation_done(lbh_index* ix) {
+    ix->mut_gen += 1;
+    HIP_TRY(hipSetDevice(ix->ctx->device));
+    HIP_TRY(hipEventRecord(ix->mut_ev, ix->ctx->stream));
+    return LBH_OK;
+}
+
+struct Exclusive {
+    lbh_index* ix;
+    std::unique_lock<std::shared_mutex> lk;
+    explicit Exclusive(lbh_index* i) : ix(i), lk(i->rw) {}
+    ~Exclusive() {
+        const std::string keep = g_err;  // the event record must not replace the caller's error text
+        if (mutation_done(ix) != LBH_OK) g_err = keep;
+    }
+};
+
+int ensure_emb16(lbh_index* ix);
+
+// run a search body under a lease; when it reports the fp16 copy out of date, bring it up to date exclusively and retry
+template <class Body>
+int with_lease(lbh_index* ix, Body&& body) {
+    for (int attempt = 0;; ++attempt) {
+        int rc;
+        {
+            Lease lease(ix);
+            rc = lease.acquire();
+            if (rc) return rc;
+            rc = body(lease.slot());
+        }
+        if (rc != LBH_NEED_EMB16) return rc;
+        if (attempt >= 8) return fail(LBH_E_INTERNAL, "the fp16 copy kept going out of date under concurrent writers");
+        Exclusive w(ix);
+        HIP_TRY(hipSetDevice(ix->ctx->device));
+        rc = ensure_emb16(ix);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(ix->ctx->stream));
+    }
+}
+
+inline bool emb16_current(const lbh_index* ix) { return ix->emb16 && ix->emb16_rows == ix->n && ix->emb16_cap >= ix->cap; }
+
 lbh_dev_index dev_view(const lbh_index* ix) {
     lbh_dev_index d;
     d.emb32 = ix->emb32;
@@ -216,7 +409,7 @@ float norm_scale(const lbh_index* ix, double qnorm) {
 // publishes the ticket last, so polling it skips the runtime's completion hand-off.  Bounded: past
 // spin_us (a hung or faulted kernel, or a very long scan) fall back to the stream, which also reports
 // device errors.
-hipError_t wait_ticket(lbh_ctx* c, const int32_t* ticket, int32_t seq) {
+hipError_t wait_ticket(lbh_ctx* c, hipStream_t stream, const int32_t* ticket, int32_t seq) {
     if (c->spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         for (int it = 0;; ++it) {
@@ -227,7 +420,7 @@ hipError_t wait_ticket(lbh_ctx* c, const int32_t* ticket, int32_t seq) {
                 break;
         }
     }
-    return hipStreamSynchronize(c->stream);
+    return hipStreamSynchronize(stream);
 }
 
 // fp16 copy (tiled, lbh_emb16_off) for the fp16 scans: allocate with the index capacity rounded up to whole 32-row
@@ -267,39 +460,36 @@ struct SearchAcc {
 };
 
 // one device pass producing up to `page` (<= 64) results; q32/q64 must already be in the workspace
-int run_page(lbh_index* ix, int page, int64_t since_ms, uint64_t tag_mask, bool allow_fast, const lbh_cursor& cur,
+int run_page(lbh_index* ix, lbh_slot* sl, int page, int64_t since_ms, uint64_t tag_mask, bool allow_fast, const lbh_cursor& cur,
              bool timing, PageOut* out, SearchAcc* acc) {
     lbh_ctx* c = ix->ctx;
-    hipStream_t s = c->stream;
+    hipStream_t s = sl->stream;
     const lbh_dev_index dv = dev_view(ix);
     const int has_since = since_ms != LBH_SINCE_NONE;
     const int grid = lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu);
     bool fast = allow_fast && !cur.active;
     for (;;) {
-        hipEvent_t e0 = timing ? ix->ev[0] : nullptr, e1 = timing ? ix->ev[1] : nullptr;
-        const int32_t seq = ix->seq = (ix->seq == INT32_MAX) ? 1 : ix->seq + 1;
+        hipEvent_t e0 = timing ? sl->ev[0] : nullptr, e1 = timing ? sl->ev[1] : nullptr;
+        const int32_t seq = sl->seq = (sl->seq == INT32_MAX) ? 1 : sl->seq + 1;
         // the fp16 scan is for unit-scale data (its range and its error bound); anything else takes the fp32 matrix
-        const float nscale = norm_scale(ix, ix->qnorm);
+        const float nscale = norm_scale(ix, sl->qnorm);
         const bool half = fast && c->scan_mode == 1 && nscale <= 1.001f && nscale >= 0.25f;
-        if (half) {
-            const int rc16 = ensure_emb16(ix);
-            if (rc16) return rc16;
-        }
+        if (half && !emb16_current(ix)) return LBH_NEED_EMB16;
         if (fast)
-            HIP_TRY(lbh_launch_search_fast(dv, half ? ix->emb16 : nullptr, ix->ws, ix->qptr, ix->qarg, page, has_since, since_ms,
+            HIP_TRY(lbh_launch_search_fast(dv, half ? ix->emb16 : nullptr, sl->ws, sl->qptr, sl->qarg, page, has_since, since_ms,
                                            tag_mask, grid, c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, e0, e1));
         else {
             const int xgrid = std::min(grid, 512);
-            HIP_TRY(lbh_launch_search_exact(dv, ix->ws, ix->qptr, ix->qarg, page, has_since, since_ms, tag_mask, cur, xgrid, seq, s, e0, e1));
+            HIP_TRY(lbh_launch_search_exact(dv, sl->ws, sl->qptr, sl->qarg, page, has_since, since_ms, tag_mask, cur, xgrid, seq, s, e0, e1));
         }
-        const lbh_result* r = ix->ws.result_host;
-        HIP_TRY(wait_ticket(c, &r->seq, seq));
-        if (timing) HIP_TRY(hipEventSynchronize(ix->ev[1]));
+        const lbh_result* r = sl->ws.result_host;
+        HIP_TRY(wait_ticket(c, s, &r->seq, seq));
+        if (timing) HIP_TRY(hipEventSynchronize(sl->ev[1]));
         acc->scan_launches += 1;
         acc->rows_scanned = ix->n;
         if (timing) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]) == hipSuccess) acc->scan_ms += ms;
+            if (hipEventElapsedTime(&ms, sl->ev[0], sl->ev[1]) == hipSuccess) acc->scan_ms += ms;
         }
         if (fast) {
             acc->path = 0;
@@ -326,14 +516,13 @@ int run_page(lbh_index* ix, int page, int64_t since_ms, uint64_t tag_mask, bool 
 }
 
 // full search for one query whose vectors are already in ws.q32 / ws.q64
-int search_loaded(lbh_index* ix, int64_t k, int64_t since_ms, uint64_t tag_mask, uint64_t* out_ids, double* out_scores,
+int search_loaded(lbh_index* ix, lbh_slot* sl, int64_t k, int64_t since_ms, uint64_t tag_mask, uint64_t* out_ids, double* out_scores,
                   uint8_t* out_keys, int64_t* out_count, lbh_stats* stats) {
-    lbh_ctx* c = ix->ctx;
     const bool timing = stats && stats->want_timing;
     SearchAcc acc;
     int64_t got = 0;
     const bool timing_total = timing && stats->want_timing >= 2;  // two more event records per call
-    if (timing_total) HIP_TRY(hipEventRecord(ix->ev[2], c->stream));
+    if (timing_total) HIP_TRY(hipEventRecord(sl->ev[2], sl->stream));
     if (k > 0 && ix->n > 0) {
         lbh_cursor cur;
         memset(&cur, 0, sizeof cur);
@@ -341,7 +530,7 @@ int search_loaded(lbh_index* ix, int64_t k, int64_t since_ms, uint64_t tag_mask,
         while (remaining > 0) {
             const int page = (int)std::min<int64_t>(remaining, LBH_MAX_PAGE);
             PageOut po;
-            int rc = run_page(ix, page, since_ms, tag_mask, true, cur, timing, &po, &acc);
+            int rc = run_page(ix, sl, page, since_ms, tag_mask, true, cur, timing, &po, &acc);
             if (rc) return rc;
             for (int i = 0; i < po.count; ++i) {
                 out_ids[got + i] = ix->id_of_row[po.rows[i]];
@@ -361,9 +550,9 @@ int search_loaded(lbh_index* ix, int64_t k, int64_t since_ms, uint64_t tag_mask,
     if (stats) {
         float total = 0.f;
         if (timing_total) {
-            HIP_TRY(hipEventRecord(ix->ev[3], c->stream));
-            HIP_TRY(hipEventSynchronize(ix->ev[3]));
-            (void)hipEventElapsedTime(&total, ix->ev[2], ix->ev[3]);
+            HIP_TRY(hipEventRecord(sl->ev[3], sl->stream));
+            HIP_TRY(hipEventSynchronize(sl->ev[3]));
+            (void)hipEventElapsedTime(&total, sl->ev[2], sl->ev[3]);
         }
         stats->path = acc.path;
         stats->rows_scanned = acc.rows_scanned;
@@ -378,8 +567,8 @@ int search_loaded(lbh_index* ix, int64_t k, int64_t since_ms, uint64_t tag_mask,
     return LBH_OK;
 }
 
-int ensure_batched_ws(lbh_index* ix) {
-    lbh_workspace& w = ix->ws;
+int ensure_batched_ws(lbh_slot* sl) {
+    lbh_workspace& w = sl->ws;
     if (w.bq_qmat) return LBH_OK;
     HIP_TRY(hipMalloc((void**)&w.bq_qmat, (size_t)LBH_BQ_MAXQ * 512));
     HIP_TRY(hipMalloc((void**)&w.bq_cand, (size_t)LBH_BQ_MAXQ * LBH_BQ_PERQ * 8));
@@ -391,8 +580,8 @@ int ensure_batched_ws(lbh_index* ix) {
     return LBH_OK;
 }
 
-int ensure_recent_ws(lbh_index* ix) {
-    lbh_workspace& w = ix->ws;
+int ensure_recent_ws(lbh_slot* sl) {
+    lbh_workspace& w = sl->ws;
     if (w.rc_result_host) return LBH_OK;
     const size_t cap = (size_t)LBH_RC_MAX_BLOCKS * LBH_MAX_PAGE;
     if (!w.rc_a) HIP_TRY(hipMalloc((void**)&w.rc_a, cap * 8));
@@ -408,12 +597,12 @@ int ensure_recent_ws(lbh_index* ix) {
     return LBH_OK;
 }
 
-int load_query(lbh_index* ix, const double* q) {
+int load_query(lbh_slot* sl, const double* q) {
     const double nrm = vec_norm(q);
     if (!(nrm <= 1e15)) return fail(LBH_E_INVALID, "query vector is not finite (or its norm exceeds 1e15)");
-    memcpy(ix->qarg.q, q, sizeof ix->qarg.q);  // travels to the GPU inside the kernel-argument segment
-    ix->qptr = nullptr;
-    ix->qnorm = nrm;
+    memcpy(sl->qarg.q, q, sizeof sl->qarg.q);  // travels to the GPU inside the kernel-argument segment
+    sl->qptr = nullptr;
+    sl->qnorm = nrm;
     return LBH_OK;
 }
 
@@ -572,23 +761,6 @@ int lbh_cosine(lbh_ctx* c, const double* a, int64_t na, const double* b, int64_t
     return LBH_OK;
 }
 
-namespace {
-int index_alloc_workspace(lbh_index* ix) {
-    lbh_workspace& w = ix->ws;
-    HIP_TRY(hipMalloc((void**)&w.q64, 512));
-    HIP_TRY(hipMalloc((void**)&w.cand, (size_t)LBH_MAX_BLOCKS * LBH_LIST_CAP * 8));
-    HIP_TRY(hipMalloc((void**)&w.xcand_ord, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 8));
-    HIP_TRY(hipMalloc((void**)&w.xcand_row, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 4));
-    HIP_TRY(hipMalloc((void**)&w.flags, 512));
-    HIP_TRY(hipHostMalloc((void**)&w.result_host, sizeof(lbh_result), hipHostMallocMapped | hipHostMallocCoherent));
-    HIP_TRY(hipHostGetDevicePointer((void**)&w.result_dev, w.result_host, 0));
-    memset(w.result_host, 0, sizeof(lbh_result));
-    HIP_TRY(hipMemset(w.flags, 0, 512));
-    for (auto& ev : ix->ev) HIP_TRY(hipEventCreate(&ev));
-    return LBH_OK;
-}
-}  // namespace
-
 int lbh_index_create(lbh_ctx* c, lbh_index** out_idx) {
     if (!c || !out_idx) return fail(LBH_E_INVALID, "bad argument");
     *out_idx = nullptr;
@@ -596,7 +768,9 @@ int lbh_index_create(lbh_ctx* c, lbh_index** out_idx) {
     lbh_index* ix = new (std::nothrow) lbh_index();
     if (!ix) return fail(LBH_E_NOMEM, "out of host memory");
     ix->ctx = c;
-    const int rc = index_alloc_workspace(ix);
+    int rc = slot_create(ix, 0, &ix->slots[0]);
+    if (!rc && hipEventCreateWithFlags(&ix->mut_ev, hipEventDisableTiming) != hipSuccess) rc = fail(LBH_E_DEVICE, "hipEventCreate failed");
+    if (!rc) rc = mutation_done(ix);
     if (rc) {
         const std::string why = g_err;  // lbh_index_destroy must not hide the reason
         lbh_index_destroy(ix);
@@ -611,16 +785,14 @@ int lbh_index_destroy(lbh_index* ix) {
     if (!ix) return LBH_OK;
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
-    lbh_workspace& w = ix->ws;
-    void* dev[] = {ix->emb16, ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, ix->order, ix->ids, w.rc_a, w.rc_b, w.rc_row, w.rc_cnt, w.q64, w.cand, w.xcand_ord, w.xcand_row,
-                   w.flags, w.bq_qmat, w.bq_cand, w.bq_total, w.bq_seed, w.bq_bfrag};
+    for (auto& sl : ix->slots) {
+        slot_destroy(sl);
+        sl = nullptr;
+    }
+    void* dev[] = {ix->emb16, ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, ix->order, ix->ids};
     for (void* p : dev)
         if (p) (void)hipFree(p);
-    for (auto& ev : ix->ev)
-        if (ev) (void)hipEventDestroy(ev);
-    if (w.result_host) (void)hipHostFree(w.result_host);
-    if (w.bq_result_host) (void)hipHostFree(w.bq_result_host);
-    if (w.rc_result_host) (void)hipHostFree(w.rc_result_host);
+    if (ix->mut_ev) (void)hipEventDestroy(ix->mut_ev);
     if (ix->staging) (void)hipHostFree(ix->staging);
     if (ix->dscratch) (void)hipFree(ix->dscratch);
     delete ix;
@@ -629,7 +801,7 @@ int lbh_index_destroy(lbh_index* ix) {
 
 int lbh_index_reserve(lbh_index* ix, int64_t capacity) {
     if (!ix || capacity < 0) return fail(LBH_E_INVALID, "bad argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    Exclusive lk(ix);
     return index_reserve_locked(ix, capacity);
 }
 
@@ -639,7 +811,7 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
     if (n == 0) return LBH_OK;
     if ((emb_f64 != nullptr) == (offsets != nullptr)) return fail(LBH_E_INVALID, "pass either emb_f64 or (utf8, offsets)");
     if (!created_ms || !hashkey) return fail(LBH_E_INVALID, "created_ms and hashkey are required");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    Exclusive lk(ix);
     lbh_ctx* c = ix->ctx;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -661,6 +833,7 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
     HIP_TRY(lbh_launch_iota_u64(ix->ids + r0, (uint64_t)ix->row_of_id.size(), n, s));
     double batch_norm = 1.0;  // K1 writes unit vectors (or zero)
     std::vector<int64_t> rel;  // must outlive the copies below: freed after the final synchronise
+    std::unique_lock<std::mutex> text_lk(c->mu, std::defer_lock);  // the context's text scratch, held until the final synchronise
     if (emb_f64) {
         batch_norm = 0.0;
         for (int64_t i = 0; i < n; ++i) batch_norm = std::max(batch_norm, vec_norm(emb_f64 + i * 64));
@@ -681,7 +854,7 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
             (void)hipStreamSynchronize(s);
             return fail(LBH_E_INVALID, "bad offsets (a text has a negative length or 2 GiB and more)");
         }
-        std::lock_guard<std::mutex> lk2(c->mu);
+        text_lk.lock();
         const int rc = ensure_ctx_scratch(c, bytes + 64, n + 1, 0);
         if (rc) return rc;
         const int64_t* offp = offsets;
@@ -727,7 +900,7 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
 
 int lbh_index_retract(lbh_index* ix, uint64_t id) {
     if (!ix) return fail(LBH_E_INVALID, "bad argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    Exclusive lk(ix);
     if (id >= ix->row_of_id.size() || ix->row_of_id[(size_t)id] < 0) return fail(LBH_E_NOTFOUND, "unknown claim id %llu", (unsigned long long)id);
     HIP_TRY(hipSetDevice(ix->ctx->device));
     const int64_t r = ix->row_of_id[(size_t)id], last = ix->n - 1;
@@ -748,7 +921,7 @@ int lbh_index_retract(lbh_index* ix, uint64_t id) {
 int lbh_index_retract_many(lbh_index* ix, int64_t n, const uint64_t* ids) {
     if (!ix || n < 0 || (n > 0 && !ids)) return fail(LBH_E_INVALID, "bad argument");
     if (n == 0) return LBH_OK;
-    std::lock_guard<std::mutex> lk(ix->mu);
+    Exclusive lk(ix);
     // rows to delete, ascending; an unknown or repeated id fails the whole call before anything changes
     std::vector<int64_t> dead((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
@@ -807,7 +980,7 @@ int lbh_index_retract_many(lbh_index* ix, int64_t n, const uint64_t* ids) {
 int lbh_index_get_embeddings(lbh_index* ix, int64_t n, const uint64_t* ids, double* out_f64) {
     if (!ix || n < 0 || (n > 0 && (!ids || !out_f64))) return fail(LBH_E_INVALID, "bad argument");
     if (n == 0) return LBH_OK;
-    std::lock_guard<std::mutex> lk(ix->mu);
+    Exclusive lk(ix);
     HIP_TRY(hipSetDevice(ix->ctx->device));
     hipStream_t s = ix->ctx->stream;
     int rc = ensure_staging(ix, n * 8);
@@ -832,7 +1005,7 @@ int lbh_index_get_embeddings(lbh_index* ix, int64_t n, const uint64_t* ids, doub
 
 int lbh_index_update_meta(lbh_index* ix, uint64_t id, int64_t created_ms, uint64_t tagmask, const uint8_t* hashkey) {
     if (!ix || !hashkey) return fail(LBH_E_INVALID, "bad argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    Exclusive lk(ix);
     if (id >= ix->row_of_id.size() || ix->row_of_id[(size_t)id] < 0) return fail(LBH_E_NOTFOUND, "unknown claim id %llu", (unsigned long long)id);
     HIP_TRY(hipSetDevice(ix->ctx->device));
     const int64_t r = ix->row_of_id[(size_t)id];
@@ -849,7 +1022,7 @@ int lbh_index_update_meta(lbh_index* ix, uint64_t id, int64_t created_ms, uint64
 int lbh_index_set_keys(lbh_index* ix, int64_t n, const uint64_t* ids, const uint8_t* hashkey) {
     if (!ix || n < 0 || (n > 0 && (!ids || !hashkey))) return fail(LBH_E_INVALID, "bad argument");
     if (n == 0) return LBH_OK;
-    std::lock_guard<std::mutex> lk(ix->mu);
+    Exclusive lk(ix);
     HIP_TRY(hipSetDevice(ix->ctx->device));
     hipStream_t s = ix->ctx->stream;
     // download, patch, upload: the key table is 32 B/claim and this path is for small graphs
@@ -870,7 +1043,7 @@ int lbh_index_set_keys(lbh_index* ix, int64_t n, const uint64_t* ids, const uint
 int lbh_index_set_order(lbh_index* ix, int64_t n, const uint64_t* ids, const uint64_t* order) {
     if (!ix || n < 0 || (n > 0 && (!ids || !order))) return fail(LBH_E_INVALID, "bad argument");
     if (n == 0) return LBH_OK;
-    std::lock_guard<std::mutex> lk(ix->mu);
+    Exclusive lk(ix);
     HIP_TRY(hipSetDevice(ix->ctx->device));
     hipStream_t s = ix->ctx->stream;
     int rc = ensure_staging(ix, n * 16);
@@ -897,7 +1070,7 @@ int lbh_index_recent(lbh_index* ix, int64_t since_ms, int64_t limit, uint64_t* o
     if (!ix || !out_count) return fail(LBH_E_INVALID, "bad argument");
     if (limit < 0) limit = 0;
     if (limit > 0 && !out_ids) return fail(LBH_E_INVALID, "output arrays are NULL");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    return with_lease(ix, [&](lbh_slot* sl) -> int {
     lbh_ctx* c = ix->ctx;
     HIP_TRY(hipSetDevice(c->device));
     *out_count = 0;
@@ -909,26 +1082,26 @@ int lbh_index_recent(lbh_index* ix, int64_t since_ms, int64_t limit, uint64_t* o
         stats->path = 3;
     }
     if (ix->n == 0) return LBH_OK;
-    int rc = ensure_recent_ws(ix);
+    int rc = ensure_recent_ws(sl);
     if (rc) return rc;
     const bool timing = stats && stats->want_timing;
     const int has_since = since_ms != LBH_SINCE_NONE;
     lbh_rcursor cur;
     memset(&cur, 0, sizeof cur);
     int64_t got = 0, remaining = std::min<int64_t>(limit, ix->n);
-    const lbh_recent_result* r = ix->ws.rc_result_host;
+    const lbh_recent_result* r = sl->ws.rc_result_host;
     bool first = true;
     int64_t anchor = ix->n;  // where the threshold seed looks: the index tail, then just below the last page's rows
     while (first || remaining > 0) {  // one pass even for limit 0: it still reports `matched`
         const int page = (int)std::max<int64_t>(1, std::min<int64_t>(remaining, LBH_MAX_PAGE));
-        const int32_t seq = ix->seq = (ix->seq == INT32_MAX) ? 1 : ix->seq + 1;
-        HIP_TRY(lbh_launch_recent(ix->created, ix->order, ix->n, ix->ws, page, has_since, since_ms, cur, anchor, c->n_cu, seq,
-                                  c->stream, timing ? ix->ev[0] : nullptr, timing ? ix->ev[1] : nullptr));
-        HIP_TRY(wait_ticket(c, &r->seq, seq));
+        const int32_t seq = sl->seq = (sl->seq == INT32_MAX) ? 1 : sl->seq + 1;
+        HIP_TRY(lbh_launch_recent(ix->created, ix->order, ix->n, sl->ws, page, has_since, since_ms, cur, anchor, c->n_cu, seq,
+                                  sl->stream, timing ? sl->ev[0] : nullptr, timing ? sl->ev[1] : nullptr));
+        HIP_TRY(wait_ticket(c, sl->stream, &r->seq, seq));
         if (timing) {
-            HIP_TRY(hipEventSynchronize(ix->ev[1]));
+            HIP_TRY(hipEventSynchronize(sl->ev[1]));
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]) == hipSuccess) stats->scan_ms += ms;
+            if (hipEventElapsedTime(&ms, sl->ev[0], sl->ev[1]) == hipSuccess) stats->scan_ms += ms;
         }
         if (stats) {
             stats->scan_launches += 1;
@@ -953,6 +1126,7 @@ int lbh_index_recent(lbh_index* ix, int64_t since_ms, int64_t limit, uint64_t* o
     *out_count = got;
     if (stats) stats->candidates = got;
     return LBH_OK;
+    });
 }
 
 int lbh_merge_topk(const int64_t* lists, int64_t n_lists, int64_t k, int64_t* out_entries, int64_t* out_count) {
@@ -989,14 +1163,14 @@ int lbh_merge_topk(const int64_t* lists, int64_t n_lists, int64_t k, int64_t* ou
 
 int lbh_index_size(lbh_index* ix, int64_t* out_live) {
     if (!ix || !out_live) return fail(LBH_E_INVALID, "bad argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::shared_lock<std::shared_mutex> lk(ix->rw);
     *out_live = ix->n;
     return LBH_OK;
 }
 
 int lbh_index_get_embedding(lbh_index* ix, uint64_t id, double* out64) {
     if (!ix || !out64) return fail(LBH_E_INVALID, "bad argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    Exclusive lk(ix);
     if (id >= ix->row_of_id.size() || ix->row_of_id[(size_t)id] < 0) return fail(LBH_E_NOTFOUND, "unknown claim id %llu", (unsigned long long)id);
     HIP_TRY(hipSetDevice(ix->ctx->device));
     const int64_t r = ix->row_of_id[(size_t)id];
@@ -1010,7 +1184,7 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
     if (!ix || nq < 0 || (nq > 0 && (!q_f64 || !out_counts))) return fail(LBH_E_INVALID, "bad argument");
     if (k < 0) k = 0;
     if (k > 0 && nq > 0 && (!out_ids || !out_scores)) return fail(LBH_E_INVALID, "output arrays are NULL");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    return with_lease(ix, [&](lbh_slot* sl) -> int {
     HIP_TRY(hipSetDevice(ix->ctx->device));
     lbh_stats total;
     memset(&total, 0, sizeof total);
@@ -1021,10 +1195,10 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
     // cores (256 queries per launch).  A query whose candidate set could not be bounded there is
     // re-run below on the single-query path, so results never depend on which path served them.
     if (nq >= 3 && keff >= 1 && keff <= LBH_BQ_KMAX && ix->n > 0) {
-        int rc = ensure_batched_ws(ix);
+        int rc = ensure_batched_ws(sl);
         if (rc) return rc;
         lbh_ctx* c = ix->ctx;
-        hipStream_t s = c->stream;
+        hipStream_t s = sl->stream;
         const lbh_dev_index dv = dev_view(ix);
         const int has_since = since_ms != LBH_SINCE_NONE;
         bool any16 = false;
@@ -1033,27 +1207,24 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
             double qn = 0.0;
             for (int q = 0; q < nb; ++q) qn = std::max(qn, vec_norm(q_f64 + (q0 + q) * 64));
             if (!(qn <= 1e15)) return fail(LBH_E_INVALID, "a query vector is not finite (or its norm exceeds 1e15)");
-            HIP_TRY(hipMemcpyAsync(ix->ws.bq_qmat, q_f64 + q0 * 64, (size_t)nb * 512, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(sl->ws.bq_qmat, q_f64 + q0 * 64, (size_t)nb * 512, hipMemcpyHostToDevice, s));
             const float nscale = norm_scale(ix, qn);
             // the fp16 kernel streams the fp16 copy of the matrix (128 B/claim, MFMA-fragment order; built on first use)
             const bool src16 = c->bq_mode == 2 && nscale >= 0.25f && nscale <= 1.001f;
-            if (src16) {
-                const int rc16 = ensure_emb16(ix);
-                if (rc16) return rc16;
-            }
+            if (src16 && !emb16_current(ix)) return LBH_NEED_EMB16;
             any16 = any16 || src16;
-            HIP_TRY(lbh_launch_search_batched(dv, src16 ? ix->emb16 : nullptr, ix->ws, nb, (int)keff, has_since, since_ms, tag_mask, c->n_cu, c->bq_mode,
+            HIP_TRY(lbh_launch_search_batched(dv, src16 ? ix->emb16 : nullptr, sl->ws, nb, (int)keff, has_since, since_ms, tag_mask, c->n_cu, c->bq_mode,
                                               nscale, s,
-                                              timing ? ix->ev[0] : nullptr, timing ? ix->ev[1] : nullptr));
+                                              timing ? sl->ev[0] : nullptr, timing ? sl->ev[1] : nullptr));
             HIP_TRY(hipStreamSynchronize(s));
             total.scan_launches += 1;
             total.rows_scanned += ix->n;
             if (timing) {
                 float ms = 0.f;
-                if (hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]) == hipSuccess) total.scan_ms += ms;
+                if (hipEventElapsedTime(&ms, sl->ev[0], sl->ev[1]) == hipSuccess) total.scan_ms += ms;
             }
             for (int i = 0; i < nb; ++i) {
-                const lbh_result* r = ix->ws.bq_result_host + i;
+                const lbh_result* r = sl->ws.bq_result_host + i;
                 if (r->overflow) continue;  // served by the single-query path below
                 const int64_t q = q0 + i;
                 for (int j = 0; j < r->count; ++j) {
@@ -1071,12 +1242,12 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
     }
     for (int64_t q = 0; q < nq; ++q) {
         if (done[(size_t)q]) continue;
-        int rc = load_query(ix, q_f64 + q * 64);
+        int rc = load_query(sl, q_f64 + q * 64);
         if (rc) return rc;
         lbh_stats st;
         memset(&st, 0, sizeof st);
         st.want_timing = stats ? stats->want_timing : 0;
-        rc = search_loaded(ix, k, since_ms, tag_mask, out_ids + q * k, out_scores + q * k, nullptr, out_counts + q,
+        rc = search_loaded(ix, sl, k, since_ms, tag_mask, out_ids + q * k, out_scores + q * k, nullptr, out_counts + q,
                            stats ? &st : nullptr);
         if (rc) return rc;
         if (stats) {
@@ -1100,6 +1271,7 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
         *stats = total;
     }
     return LBH_OK;
+    });
 }
 
 int lbh_index_search_text(lbh_index* ix, const uint8_t* utf8, int64_t len, int64_t k, int64_t since_ms, uint64_t tag_mask,
@@ -1108,35 +1280,31 @@ int lbh_index_search_text(lbh_index* ix, const uint8_t* utf8, int64_t len, int64
     if (len >= (int64_t)0x7FFFFF00) return fail(LBH_E_INVALID, "query too long");
     if (k < 0) k = 0;
     if (k > 0 && (!out_ids || !out_scores)) return fail(LBH_E_INVALID, "output arrays are NULL");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    return with_lease(ix, [&](lbh_slot* sl) -> int {
     lbh_ctx* c = ix->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    {
-        std::lock_guard<std::mutex> lk2(c->mu);
-        int rc = ensure_ctx_scratch(c, len + 64, 2, 0);
-        if (rc) return rc;
-        rc = ensure_staging(ix, len + 64);
-        if (rc) return rc;
-        int64_t* ho = reinterpret_cast<int64_t*>(ix->staging);
-        ho[0] = 0;
-        ho[1] = len;
-        uint8_t* ht = reinterpret_cast<uint8_t*>(ho + 2);
-        if (len) memcpy(ht, utf8, (size_t)len);
-        if (len) HIP_TRY(hipMemcpyAsync(c->d_text, ht, (size_t)len, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(c->d_off, ho, 16, hipMemcpyHostToDevice, s));
-        // embed(query) (lb/context_graph.py:104) straight into the search workspace
-        HIP_TRY(lbh_launch_embed(c->d_text, c->d_off, 1, ix->ws.q64, nullptr, s));
-        ix->qptr = ix->ws.q64;
-        ix->qnorm = 1.0;  // K1 output: a unit vector (or zero)
-        if (out_qvec64) {
-            HIP_TRY(hipMemcpyAsync(out_qvec64, ix->ws.q64, 512, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-        }
-        // no sync otherwise: the scan is stream-ordered behind the embed kernel, and the staging
-        // area is only rewritten under ix->mu after this search's final synchronize
+    hipStream_t s = sl->stream;
+    int rc = slot_text_buffers(sl, len + 64);
+    if (rc) return rc;
+    int64_t* ho = reinterpret_cast<int64_t*>(sl->staging);
+    ho[0] = 0;
+    ho[1] = len;
+    uint8_t* ht = reinterpret_cast<uint8_t*>(ho + 2);
+    if (len) memcpy(ht, utf8, (size_t)len);
+    if (len) HIP_TRY(hipMemcpyAsync(sl->d_text, ht, (size_t)len, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(sl->d_off, ho, 16, hipMemcpyHostToDevice, s));
+    // embed(query) (lb/context_graph.py:104) straight into the search workspace
+    HIP_TRY(lbh_launch_embed(sl->d_text, sl->d_off, 1, sl->ws.q64, nullptr, s));
+    sl->qptr = sl->ws.q64;
+    sl->qnorm = 1.0;  // K1 output: a unit vector (or zero)
+    if (out_qvec64) {
+        HIP_TRY(hipMemcpyAsync(out_qvec64, sl->ws.q64, 512, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
     }
-    return search_loaded(ix, k, since_ms, tag_mask, out_ids, out_scores, nullptr, out_count, stats);
+    // no sync otherwise: the scan is stream-ordered behind the embed kernel, and the slot's staging area is only
+    // rewritten by its next holder, after this search's final wait
+    return search_loaded(ix, sl, k, since_ms, tag_mask, out_ids, out_scores, nullptr, out_count, stats);
+    });
 }
 
 int lbh_search_dev_noalloc(lbh_ctx* c, const float* emb32_dev, const double* emb64_dev, const int64_t* created_ms_dev,
@@ -1179,11 +1347,12 @@ int lbh_index_search_shard(lbh_index* ix, const double* q_f64, int64_t k, int64_
     if (!ix || !q_f64 || !out_count) return fail(LBH_E_INVALID, "bad argument");
     if (k < 0) k = 0;
     if (k > 0 && (!out_ids || !out_scores || !out_keys)) return fail(LBH_E_INVALID, "output arrays are NULL");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    HIP_TRY(hipSetDevice(ix->ctx->device));
-    int rc = load_query(ix, q_f64);
-    if (rc) return rc;
-    return search_loaded(ix, k, since_ms, tag_mask, out_ids, out_scores, out_keys, out_count, stats);
+    return with_lease(ix, [&](lbh_slot* sl) -> int {
+        HIP_TRY(hipSetDevice(ix->ctx->device));
+        int rc = load_query(sl, q_f64);
+        if (rc) return rc;
+        return search_loaded(ix, sl, k, since_ms, tag_mask, out_ids, out_scores, out_keys, out_count, stats);
+    });
 }
 
 }  // extern "C"
@@ -1317,12 +1486,14 @@ int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, i
     if (k < 0) k = 0;
     if (k > 0 && (!out_gids || !out_scores)) return fail(LBH_E_INVALID, "output arrays are NULL");
     *out_count = 0;
-    std::lock_guard<std::mutex> lk(ix->mu);
+    // collectives of one communicator are issued in the same order on every rank: one sharded search at a time per
+    // communicator (taken before the index lease; mutators never take it)
     std::lock_guard<std::mutex> lk2(cm->mu);
+    return with_lease(ix, [&](lbh_slot* sl) -> int {
     lbh_ctx* c = ix->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    int rc = load_query(ix, q_f64);
+    hipStream_t s = sl->stream;
+    int rc = load_query(sl, q_f64);
     if (rc) return rc;
     if (stats) {
         const int32_t wt = stats->want_timing;
@@ -1343,23 +1514,20 @@ int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, i
         const int has_since = since_ms != LBH_SINCE_NONE;
         const int page = (int)k;
         const lbh_xchg xc{cm->send_dev, gid_mul, gid_add};
-        const float nscale = norm_scale(ix, ix->qnorm);
-        const int32_t seq = ix->seq = (ix->seq == INT32_MAX) ? 1 : ix->seq + 1;
+        const float nscale = norm_scale(ix, sl->qnorm);
+        const int32_t seq = sl->seq = (sl->seq == INT32_MAX) ? 1 : sl->seq + 1;
         HIP_TRY(hipMemsetAsync(cm->send_dev, 0, 48, s));  // count 0 if this shard is empty / nothing passes
         if (ix->n > 0) {
             const int grid = lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu);
             const bool half = c->scan_mode == 1 && nscale <= 1.001f && nscale >= 0.25f;
-            if (half) {
-                rc = ensure_emb16(ix);
-                if (rc) return rc;
-            }
-            HIP_TRY(lbh_launch_search_fast(dv, half ? ix->emb16 : nullptr, ix->ws, nullptr, ix->qarg, page, has_since, since_ms, tag_mask, grid,
-                                           c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, timing ? ix->ev[0] : nullptr,
-                                           timing ? ix->ev[1] : nullptr, &xc));
+            if (half && !emb16_current(ix)) return LBH_NEED_EMB16;
+            HIP_TRY(lbh_launch_search_fast(dv, half ? ix->emb16 : nullptr, sl->ws, nullptr, sl->qarg, page, has_since, since_ms, tag_mask, grid,
+                                           c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, timing ? sl->ev[0] : nullptr,
+                                           timing ? sl->ev[1] : nullptr, &xc));
             lbh_cursor cur;
             memset(&cur, 0, sizeof cur);
-            HIP_TRY(lbh_launch_search_exact(dv, ix->ws, nullptr, ix->qarg, page, has_since, since_ms, tag_mask, cur, std::min(grid, 512), seq, s,
-                                            nullptr, nullptr, &xc, &ix->ws.result_dev->overflow));
+            HIP_TRY(lbh_launch_search_exact(dv, sl->ws, nullptr, sl->qarg, page, has_since, since_ms, tag_mask, cur, std::min(grid, 512), seq, s,
+                                            nullptr, nullptr, &xc, &sl->ws.result_dev->overflow));
             if (stats) {
                 stats->rows_scanned = ix->n;
                 stats->bytes_per_row = (half ? 128 : 256) + (has_since ? 8 : 0) + (tag_mask ? 8 : 0);
@@ -1371,14 +1539,14 @@ int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, i
         int32_t* ticket_host = reinterpret_cast<int32_t*>(cm->recv_host + (size_t)LBH_XCHG_WORDS * W);
         int32_t* ticket_dev = reinterpret_cast<int32_t*>(cm->recv_host_dev + (size_t)LBH_XCHG_WORDS * W);
         HIP_TRY(lbh_launch_xchg_publish(cm->recv_dev, cm->recv_host_dev, LBH_XCHG_WORDS * W, ticket_dev, xseq, s));
-        HIP_TRY(wait_ticket(c, ticket_host, xseq));
+        HIP_TRY(wait_ticket(c, s, ticket_host, xseq));
         if (timing && ix->n > 0) {
-            HIP_TRY(hipEventSynchronize(ix->ev[1]));
+            HIP_TRY(hipEventSynchronize(sl->ev[1]));
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]) == hipSuccess) stats->scan_ms = ms;
+            if (hipEventElapsedTime(&ms, sl->ev[0], sl->ev[1]) == hipSuccess) stats->scan_ms = ms;
         }
         if (stats && ix->n > 0) {
-            const lbh_result* r = ix->ws.result_host;
+            const lbh_result* r = sl->ws.result_host;
             stats->candidates = r->candidates;
         }
         // lists are LBH_MAX_PAGE + 1 rows apart; lbh_merge_topk wants (kk + 1) rows: compact in place on the host copy
@@ -1414,7 +1582,7 @@ int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, i
         std::vector<double> sc((size_t)k);
         std::vector<uint8_t> keys((size_t)k * 32);
         int64_t got = 0;
-        rc = search_loaded(ix, k, since_ms, tag_mask, ids.data(), sc.data(), keys.data(), &got, stats);
+        rc = search_loaded(ix, sl, k, since_ms, tag_mask, ids.data(), sc.data(), keys.data(), &got, stats);
         if (rc) return rc;
         int64_t* sh = cm->big_send_host;
         memset(sh, 0, (size_t)(k + 1) * 48);
@@ -1445,6 +1613,7 @@ int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, i
     }
     *out_count = cnt;
     return LBH_OK;
+    });
 }
 
 }  // extern "C"

@@ -143,6 +143,8 @@ class ShardedContextGraph(ContextGraph):
     (<= 32 UTF-8 bytes, no NUL).  Anything else raises ``ValueError`` at the next query (rank keys are private to one
     index and cannot be merged across shards)."""
 
+    _overlap_searches = False  # a search here is a collective: every rank must issue them in the same order, one at a time
+
     def __init__(self, rank: int, world: int, *, comm=None, group=None, _index_factory=None, _embed=None) -> None:
         super().__init__()
         if not 0 <= int(rank) < int(world):
