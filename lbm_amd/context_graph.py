@@ -268,14 +268,16 @@ class _EmbeddingCacheView:
     def __contains__(self, h) -> bool:
         g = self._g
         g._sync()
-        return h in g._id_of or h in g._parked
+        return (h in g._id_of and h not in g._unscored) or h in g._parked or h in g._pending_text
 
     @_locked_g
     def __getitem__(self, h) -> List[float]:
         g = self._g
         g._sync()
-        if h in g._id_of:
+        if h in g._id_of and h not in g._unscored:
             return g._index.get_embedding(g._id_of[h]).tolist()
+        if h in g._pending_text:  # add_claim'ed, then taken out of the ranking by hand before any query: embed it now
+            g._parked[h] = _hip.embed_batch([g._pending_text.pop(h)])[0].copy()
         if h in g._parked:
             return g._parked[h].tolist()
         raise KeyError(h)
@@ -300,6 +302,7 @@ class _EmbeddingCacheView:
         if not np.all(np.isfinite(v)) or too_big:
             raise ValueError("embedding must be finite with a norm of at most 1e15")
         g._drop_row(h, park=False)
+        g._pending_text.pop(h, None)
         g._parked[h] = v
         g._touch(h)
 
@@ -307,7 +310,7 @@ class _EmbeddingCacheView:
     def pop(self, h, *default):
         g = self._g
         g._sync()
-        if h in g._id_of or h in g._parked:
+        if (h in g._id_of and h not in g._unscored) or h in g._parked or h in g._pending_text:
             val = self[h]
             g._drop_row(h, park=False)
             g._parked.pop(h, None)
@@ -325,7 +328,8 @@ class _EmbeddingCacheView:
     def keys(self) -> List[str]:
         g = self._g
         g._sync()
-        return list(g._id_of.keys()) + [h for h in g._parked if h not in g._id_of]
+        return ([h for h in g._id_of if h not in g._unscored] + [h for h in g._parked if h not in g._id_of]
+                + [h for h in g._pending_text if h not in g._id_of and h not in g._parked])
 
     @_locked_g
     def __iter__(self) -> Iterator[str]:
@@ -364,6 +368,10 @@ class ContextGraph:
         self._meta: Dict[str, Tuple[int, int]] = {}  # hash -> (created_ms, tagmask) as stored on device
         self._parked: Dict[str, np.ndarray] = {}     # cached vectors of claims currently not scanned
         self._discard: Dict[str, None] = {}          # hashes whose cached vector retract() / add_claim() dropped since the last sync
+        # Claims that reached the device without passing through add_claim / from_snapshot (inserted into ``claims`` by
+        # hand, or made live again after retract()): the reference has no cache entry for them until a compile() scores
+        # them (:113-117).  hash -> the text their row was embedded from.
+        self._unscored: Dict[str, str] = {}
         self._tag_bits: Dict[str, int] = {}
         self._tag_overflow = False
         self._key_mode = "hex"   # "hex" | "raw" | "rank": how claim hashes become 32-byte ordering keys (module docstring)
@@ -450,11 +458,12 @@ class ContextGraph:
         cid = self._id_of.pop(h, None)
         if cid is None:
             return
-        if park:
+        if park and h not in self._unscored:
             self._parked[h] = self._index.get_embedding(cid)
         self._index.retract(cid)
         self._hash_of.pop(cid, None)
         self._meta.pop(h, None)
+        self._unscored.pop(h, None)
 
     @_locked
     def _sync(self) -> None:
@@ -496,7 +505,10 @@ class ContextGraph:
                 continue
             c = claims.get(h)
             if c is None or getattr(c, "retracted", False):
-                drop_park.append(h)
+                # a claim the reference never scored has no cached vector to keep
+                (drop_free if h in self._unscored else drop_park).append(h)
+            elif h in self._unscored and getattr(c, "text", None) != self._unscored[h]:
+                drop_free.append(h)  # still uncached in the reference: it will embed the text as it is when first scored
         if drop_park or drop_free:
             index = self._index
             vecs = index.get_embeddings([self._id_of[h] for h in drop_park]) if drop_park else None
@@ -506,6 +518,7 @@ class ContextGraph:
             for h in drop_park + drop_free:
                 self._hash_of.pop(self._id_of.pop(h), None)
                 self._meta.pop(h, None)
+                self._unscored.pop(h, None)
         for h in dirty:
             if self._discard.pop(h, 0) is None:
                 self._parked.pop(h, None)
@@ -515,8 +528,7 @@ class ContextGraph:
         for h in dirty:
             c = claims.get(h)
             if c is None or getattr(c, "retracted", False):
-                self._pending_text.pop(h, None)
-                continue
+                continue  # a text captured by add_claim stays pending: the reference's cache still holds its vector
             if h in self._id_of:
                 cm, tm = int(c.created_ms), self._tagmask(c.tags)
                 if self._meta.get(h) != (cm, tm):
@@ -550,8 +562,9 @@ class ContextGraph:
             keys = self._keys_of(hs)
             ids = self._index.add_texts(blob, offsets, created, tmask, keys)
             self._register(hs, ids, created, tmask)
-            for h in hs:
-                self._pending_text.pop(h, None)
+            for h, t, _ in new_text:
+                if self._pending_text.pop(h, None) is None:
+                    self._unscored[h] = t
         if self._rank_keys and (self._keys_stale or new_vec or new_text):
             self._refresh_rank_keys()
 
@@ -645,6 +658,21 @@ class ContextGraph:
         """Ranking only: (claim hashes, fp64 scores) in the reference's order."""
         return self._rank(query, top_k, since_ms, tags, stats)
 
+    def _mark_scored(self, since_ms, tags) -> None:
+        """lb/context_graph.py:106-117: a compile() caches the vector of every live claim it scores (those that pass the
+        time filter; with the ``tags`` extension, those that also pass it)."""
+        if not self._unscored:
+            return
+        if since_ms is None and tags is None:
+            self._unscored.clear()
+            return
+        want = set(tags) if tags is not None else None
+        for h in list(self._unscored):
+            c = self.claims.get(h)
+            if c is None or (since_ms is not None and c.created_ms < since_ms) or (want is not None and not (want & set(c.tags))):
+                continue
+            del self._unscored[h]
+
     def _filters(self, since_ms, tags) -> Tuple[int, int, bool]:
         """(since for the C ABI, tag mask, provably-empty flag)."""
         if since_ms is None:
@@ -669,6 +697,7 @@ class ContextGraph:
     def _rank(self, query, top_k, since_ms, tags, stats=None) -> Tuple[List[str], List[float]]:
         with self._lock:
             self._sync()
+            self._mark_scored(since_ms, tags)
             k = max(0, int(top_k))  # :121
             since, tag_mask, empty = self._filters(since_ms, tags)
             if empty:
@@ -742,6 +771,8 @@ class ContextGraph:
         in one K1 launch and ranked in one pass over the claim matrix on the matrix cores (K3).  Each
         element equals ``compile(q, top_k=..., since_ms=..., tags=...)`` exactly (``lazy=True``: as ``LazyContext``)."""
         self._sync()
+        if queries:
+            self._mark_scored(since_ms, tags)
         k = max(0, int(top_k))
         since, tag_mask, empty = self._filters(since_ms, tags)
         index = self._index
@@ -767,5 +798,8 @@ class ContextGraph:
         g = ContextGraph()
         claims = s.get("claims", {}) or {}
         for h, cd in claims.items():
-            g.claims[h] = Claim.from_dict(cd)
+            c = Claim.from_dict(cd)
+            g.claims[h] = c
+            if not c.retracted:
+                g._pending_text[h] = c.text  # :146-147: cached from the text as loaded
         return g

@@ -186,6 +186,7 @@ class ShardedContextGraph(ContextGraph):
         from . import _hip
         with self._lock:
             self._sync()
+            self._mark_scored(since_ms, tags)
             k = max(0, int(top_k))
             since, tag_mask, empty = self._filters(since_ms, tags)
             index = self._index

@@ -260,6 +260,19 @@ def test_randomised_incremental_ops_vs_oracle(hip, seed, hex_hashes, smode):
             if h in og.claims:
                 del g.claims[h]; del og.claims[h]
                 known.remove(h)
+        elif r < 0.81:  # a claim put into the dict by hand: the reference embeds it when a compile first scores it (:113-117)
+            from lbm_amd.context_graph import Claim
+            h = new_hash() if rnd.random() < 0.7 else rnd.choice(known)
+            t, tg, ms = text(), rnd.sample(tags_pool, rnd.randint(0, 2)), rnd.randint(0, 50)
+            g.claims[h] = Claim(h, t, list(tg), ms, [])
+            og.claims[h] = orc.OracleClaim(h, t, list(tg), ms, [], None)
+            if h not in known:
+                known.append(h)
+        elif r < 0.83:  # text edits only matter for claims the reference has not cached yet
+            h = rnd.choice(known)
+            if h in og.claims:
+                t = text()
+                g.claims[h].text = t; og.claims[h].text = t
         else:
             q = " ".join(rnd.choice(vocab) for _ in range(rnd.randint(0, 3)))
             kw = {"top_k": rnd.choice([0, 1, 3, 8, 8, 8, 20, 100])}
@@ -275,6 +288,10 @@ def test_randomised_incremental_ops_vs_oracle(hip, seed, hex_hashes, smode):
                 qs = [q, rnd.choice(vocab), rnd.choice(vocab) + " " + rnd.choice(vocab), ""]
                 assert g.compile_many(qs, **kw) == [og.compile(x, **kw) for x in qs], (step, qs, kw)
             n_queries += 1
+        if step % 23 == 0:  # the cache view holds exactly the hashes the reference's cache holds, with the same vectors
+            assert sorted(g._embedding_cache.keys()) == sorted(og._embedding_cache), step
+            for h in list(og._embedding_cache)[:3]:
+                assert hexes(g._embedding_cache[h]) == hexes(og._embedding_cache[h]), (step, h)
     hip.set_option("scan_mode", 0)
     assert n_queries > 100
 
