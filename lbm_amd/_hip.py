@@ -160,11 +160,40 @@ def _check(rc: int) -> None:
 
 
 def default_device() -> int:
+    """The GPU this process drives.  ``LB_HIP_DEVICES`` (the reference's ``LB_*`` style, lb/config.py:49-235) lists the
+    ordinals a node may use, e.g. "0,1,2,3": rank ``LOCAL_RANK`` takes entry ``LOCAL_RANK`` (one process per GPU), a
+    single process the first.  Without it: ``LBM_HIP_DEVICE``, else ``LOCAL_RANK``, else 0."""
+    devs = os.environ.get("LB_HIP_DEVICES", "").strip()
+    if devs:
+        try:
+            lst = [int(x) for x in devs.replace(" ", "").split(",") if x != ""]
+        except ValueError:
+            raise HipBackendError(f"LB_HIP_DEVICES={devs!r}: expected a comma-separated list of GPU ordinals") from None
+        if not lst or min(lst) < 0:
+            raise HipBackendError(f"LB_HIP_DEVICES={devs!r}: expected a comma-separated list of GPU ordinals")
+        lr = os.environ.get("LOCAL_RANK", "").strip()
+        i = int(lr) if lr else 0
+        if i >= len(lst):
+            raise HipBackendError(f"LB_HIP_DEVICES lists {len(lst)} GPUs but LOCAL_RANK is {i}")
+        return lst[i]
     for var in ("LBM_HIP_DEVICE", "LOCAL_RANK"):
         v = os.environ.get(var)
         if v is not None and v.strip() != "":
             return int(v)
     return 0
+
+
+def check_backend_choice() -> None:
+    """``LB_RETRIEVAL_BACKEND`` = auto | hip | python.  This package IS the HIP backend and carries no CPU path, so
+    "auto" and "hip" mean the same (fail loudly without liblbhip.so + an MI355X) and "python" is refused: a deployment
+    that wants the reference's Python loop imports ``lb.latent`` / ``lb.context_graph`` instead of this package."""
+    v = os.environ.get("LB_RETRIEVAL_BACKEND", "auto").strip().lower() or "auto"
+    if v in ("auto", "hip"):
+        return
+    if v == "python":
+        raise HipBackendError("LB_RETRIEVAL_BACKEND=python: lbm_amd has no CPU path (import the reference's lb.latent / "
+                              "lb.context_graph for that); set it to 'hip' or 'auto' to use this package")
+    raise HipBackendError(f"LB_RETRIEVAL_BACKEND={v!r}: expected auto, hip or python")
 
 
 def context():
@@ -173,6 +202,7 @@ def context():
     L = load_library()
     with _lib_lock:
         if _ctx is None:
+            check_backend_choice()
             dev = (ctypes.c_int * 1)(default_device())
             h = _vp()
             _check(L.lbh_init(dev, 1, ctypes.byref(h)))

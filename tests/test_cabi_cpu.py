@@ -95,3 +95,32 @@ def test_synth_generator_is_deterministic_and_well_formed():
     assert a.created_ms[3] == synth.BASE_MS + 3000
     qs = synth.make_queries(5)
     assert all(3 <= len(q.split()) <= 6 for q in qs) and qs == synth.make_queries(5)
+
+
+def test_env_knobs_device_list_and_backend_choice(monkeypatch):
+    """LB_HIP_DEVICES / LB_RETRIEVAL_BACKEND (the reference's LB_* style): host logic only."""
+    for var in ("LB_HIP_DEVICES", "LBM_HIP_DEVICE", "LOCAL_RANK", "LB_RETRIEVAL_BACKEND"):
+        monkeypatch.delenv(var, raising=False)
+    assert _hip.default_device() == 0
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert _hip.default_device() == 3
+    monkeypatch.setenv("LB_HIP_DEVICES", "4, 5,6,7")
+    assert _hip.default_device() == 7
+    monkeypatch.setenv("LOCAL_RANK", "4")
+    with pytest.raises(_hip.HipBackendError, match="lists 4 GPUs"):
+        _hip.default_device()
+    monkeypatch.delenv("LOCAL_RANK")
+    assert _hip.default_device() == 4
+    monkeypatch.setenv("LB_HIP_DEVICES", "0,x")
+    with pytest.raises(_hip.HipBackendError, match="comma-separated"):
+        _hip.default_device()
+    _hip.check_backend_choice()
+    for ok in ("auto", "hip", "HIP"):
+        monkeypatch.setenv("LB_RETRIEVAL_BACKEND", ok)
+        _hip.check_backend_choice()
+    monkeypatch.setenv("LB_RETRIEVAL_BACKEND", "python")
+    with pytest.raises(_hip.HipBackendError, match="no CPU path"):
+        _hip.check_backend_choice()
+    monkeypatch.setenv("LB_RETRIEVAL_BACKEND", "cuda")
+    with pytest.raises(_hip.HipBackendError, match="expected auto, hip or python"):
+        _hip.check_backend_choice()
