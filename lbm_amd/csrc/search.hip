@@ -1197,13 +1197,13 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
 //     below), so there is no candidate buffer to compact: the rare hits go to a 256-entry per-wave staging list in LDS
 //     (ballot-prefix append) that is flushed to the queries' flat lists in HBM with one atomic per entry -- in the
 //     steady state once, at the end of the kernel.  A hit stalls only the wave that found it.
-// Passes (lbh_launch_search_batched_tiled): (1) DENSE: every score of <= 8192 rows, taken as 256 tiles spread evenly
-// over the index, is written to the lists; seed_batched_kernel turns each query's k-th best into a threshold (a
-// subset's k-th best, minus the margin, never exceeds the final cut).  (2) zero or more intermediate passes over
-// evenly spread subsets, each R times larger than the last, each starting from the previous pass's thresholds: the
-// number of rows above the k-th best of a 1/R subset is about k R whatever the score distribution (order statistics
-// of an evenly spread subset), so R is chosen to keep that near 2048 / a list of 8192.  (3) the full pass.  At 10 M
-// claims, top-8: 8192 rows -> 286 k rows -> 10 M rows, ~280 list entries per query and pass.
+// Passes (launch_batched_tiled): (1) SAMPLE: scan_batched_max_kernel runs the same loop over 1/14 of the tiles, spread
+// evenly over the index, and keeps only group maxima; seed_batched_kernel turns the k-th largest of a query's group maxima
+// into its threshold (a lower bound of the corpus's k-th best score, minus the margin, never exceeds the final cut).
+// (2) the full pass from those thresholds: about 14 k rows per query reach them, whatever the score distribution.
+// A corpus of <= 8192 rows skips (1): every row of every query is listed.  (Round 2 started with a DENSE pass that listed
+// every score of 8192 rows, a sort, and an intermediate pass over 286 k rows: 103 us of kernels at 10 M claims where
+// the sample pass + seed take 38 us, and three launches fewer.)
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -1219,11 +1219,16 @@ constexpr int K3T_STAGE = 256;      // per-wave staging list (entries)
 #define K3T_RING 2                  // claim tiles in flight per wave (register sets of 16 VGPRs)
 #endif
 #define K3T_WPS (K3T_BLOCKS_PER_CU * K3T_THREADS / 256)  // waves per SIMD the register budget is sized for
-constexpr int K3T_DENSE_TILES = BQ_PERQ / 32;  // tiles whose every score fits a query's list
+
 
 // B operand image: [group g][k-step s][lane] x 16 B = dims 16 s + 8 h .. + 7 of query 32 g + j as fp16 (one rounding
 // from the fp64 query); queries >= nq are zero
-__global__ void prep_bfrag_kernel(const double* __restrict__ qmat, int nq, f16x8* __restrict__ bfrag) {
+__global__ void prep_bfrag_kernel(const double* __restrict__ qmat, int nq, f16x8* __restrict__ bfrag, int32_t* __restrict__ qtotal,
+                                  int32_t* __restrict__ flags) {
+    if (blockIdx.x == 0) {  // first kernel of a batched search: also clears the per-query counters (no memset launches)
+        qtotal[threadIdx.x * BQ_QT] = 0;
+        if (threadIdx.x < 4) flags[threadIdx.x] = 0;
+    }
     const int lane = threadIdx.x & 63, s = (threadIdx.x >> 6) & 3, g = blockIdx.x;
     const int j = lane & 31, h = lane >> 5, q = 32 * g + j;
     f16x8 v;
@@ -1359,9 +1364,14 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
 #pragma unroll
         for (int s = 0; s < 4; ++s) a[s] = __builtin_nontemporal_load(p + s * 64);
     };
-    auto load_b = [&](f32x4 (&b)[4], int g) {
+    auto load_b_lds = [&](f32x4 (&b)[4], int g) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) b[s] = ldsb[(g * 4 + s) * 64 + lane];
+    };
+    auto load_b = [&](f32x4 (&b)[4], int g) {
+#ifndef K3T_NOBREAD  // timing-only build: the B fragments are read once (what the scan costs without the LDS traffic)
+        load_b_lds(b, g);
+#endif
     };
     // one 32 x 32 block: 4 MFMAs, lane maximum as a 3-level tree of v_max3_f32, one compare, one wave vote
     auto block = [&](const f32x4 (&araw)[4], const f32x4 (&braw)[4], int g, int64_t row0) {
@@ -1392,7 +1402,10 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
     // one tile against every query group; the next group's B fragments are read from LDS while this group's MFMAs run
     // (two register sets, ping-pong; after the last group the prefetch wraps to group 0 for the next tile)
     f32x4 b0[4], b1[4];
-    load_b(b0, 0);
+    load_b_lds(b0, 0);
+#ifdef K3T_NOBREAD
+    load_b_lds(b1, 0);
+#endif
     auto process = [&](const f32x4 (&araw)[4], int64_t i) {
         const int64_t row0 = tile_of(i) * 32;
         for (int g = 0; g < ngroups; g += 2) {
@@ -1425,50 +1438,121 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
     if (cnt > 0) k3t_flush(se, sq, cnt, lane, cand3, qtotal);
 }
 
-// DENSE pass: every score of the selected tiles (at most K3T_DENSE_TILES, one per wave) goes to slot (i, row) of its
-// query's list, rows that do not exist or fail the since / tag filters as 0 (below every real score).
-__global__ __launch_bounds__(256) void scan_batched_dense_kernel(
+// SAMPLE pass: group maxima instead of candidates.  The k-th largest of the maxima of G disjoint groups of rows is a
+// lower bound of the k-th best score of the corpus (those k maxima belong to k distinct rows), so it seeds the thresholds
+// of the full pass without listing, sorting or compacting anything: a workgroup runs the scan loop of the kernel above
+// over its share of an evenly spread sample of tiles, every lane keeps one running maximum per query group in a register,
+// and the workgroup writes ONE value per query -- slot blockIdx.x of the query's list, in the list's entry format, 0 when
+// no row of the group passes the filters -- for seed_batched_kernel to pick the k-th largest of.  Scores come out of the
+// same instruction sequence on the same operands as in the full pass, hence bit-identical.
+__global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_max_kernel(
     lbh_dev_index ix, const f32x4* __restrict__ emb16t, const f32x4* __restrict__ bfrag, int nq, int has_since, int64_t since_ms,
     uint64_t tag_mask, int64_t n_tiles, int64_t n_sel, uint64_t step_q32, uint64_t* __restrict__ cand3) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ f32x4 ldsb[8 * 4 * 64];
+    __shared__ uint32_t blkmax[BQ_MAXQ];
+    __shared__ float wmax[K3T_WAVES][8 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
-    if (i >= n_sel) return;
-    int64_t tile = (int64_t)(((unsigned __int128)(uint64_t)i * step_q32) >> 32);
-    tile = tile < n_tiles ? tile : n_tiles - 1;
-    const int64_t row0 = tile * 32, n = ix.n;
-    f16x8 a[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) a[s] = __builtin_bit_cast(f16x8, emb16t[tile * 256 + s * 64 + lane]);
-    bool rv = false;
-    if (lane < 32) {
-        const int64_t r = row0 + lane;
-        rv = r < n;
-        if (has_since) rv = rv && ix.created[rv ? r : 0] >= since_ms;
-        if (tag_mask) rv = rv && (ix.tags[r < n ? r : 0] & tag_mask) != 0;
-    }
-    const uint32_t rmask = (uint32_t)__ballot(rv);
     const int ngroups = (nq + 31) >> 5;
-    for (int g = 0; g < ngroups; ++g) {
+    const int64_t n = ix.n;
+    const bool filtered = has_since || tag_mask;
+    for (int i = tid; i < ngroups * 256; i += K3T_THREADS) ldsb[i] = bfrag[i];
+    for (int q = tid; q < BQ_MAXQ; q += K3T_THREADS) blkmax[q] = 0u;
+    __syncthreads();
+    auto tile_of = [&](int64_t i) -> int64_t {
+        const int64_t t = (int64_t)(((unsigned __int128)(uint64_t)i * step_q32) >> 32);
+        return t < n_tiles ? t : n_tiles - 1;
+    };
+    auto load_tile = [&](f32x4 (&a)[4], int64_t i) {
+        const int64_t t = tile_of(i < n_sel ? i : n_sel - 1);
+        const f32x4* p = emb16t + t * 256 + lane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[s] = __builtin_nontemporal_load(p + s * 64);
+    };
+    // running maxima: one LDS word per (query group, lane), private to the wave (registers would need a fully unrolled
+    // group loop, and the compiler then hoists all 8 groups' B fragments: 266 spilled registers)
+    float* gmax = wmax[wave];
+    for (int g = 0; g < 8; ++g) gmax[g * 64 + lane] = -__builtin_inff();
+    auto load_b = [&](f32x4 (&b)[4], int g) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[s] = ldsb[(g * 4 + s) * 64 + lane];
+    };
+    uint32_t rmask = 0xFFFFFFFFu;
+    bool masked = false;
+    auto block = [&](const f32x4 (&araw)[4], const f32x4 (&braw)[4], int g) {
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], __builtin_bit_cast(f16x8, bfrag[(g * 4 + s) * 64 + lane]), acc, 0, 0, 0);
-        const int q = 32 * g + j;
-        if (q < nq) {
-            uint64_t* dst = cand3 + (size_t)q * BQ_PERQ + i * 32;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, araw[s]), __builtin_bit_cast(f16x8, braw[s]), acc, 0, 0, 0);
+        if (masked) {  // wave-uniform: filters, or the index's last tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rowbit = (r & 3) + 8 * (r >> 2) + 4 * h;
-                dst[rowbit] = ((rmask >> rowbit) & 1u) ? (((uint64_t)lbh_ord32(acc[r]) << 32) | (uint32_t)(row0 + rowbit)) : 0ull;
+                if (!((rmask >> rowbit) & 1u)) acc[r] = -__builtin_inff();
             }
         }
+        const float m0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
+        const float m1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
+        const float m2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]);
+        const float m3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
+        const float m4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
+        const float m5 = __builtin_fmaxf(__builtin_fmaxf(m0, m1), m2);
+        const float m6 = __builtin_fmaxf(__builtin_fmaxf(m3, m4), acc[15]);
+        float* slot = &gmax[g * 64 + lane];
+        *slot = __builtin_fmaxf(*slot, __builtin_fmaxf(m5, m6));
+    };
+    f32x4 b0[4], b1[4];
+    load_b(b0, 0);
+    auto process = [&](const f32x4 (&araw)[4], int64_t i) {
+        const int64_t row0 = tile_of(i) * 32;
+        masked = filtered || row0 + 32 > n;
+        if (masked) {
+            bool rv = false;
+            if (lane < 32) {
+                const int64_t r = row0 + lane;
+                rv = r < n;
+                if (has_since) rv = rv && ix.created[rv ? r : 0] >= since_ms;
+                if (tag_mask) rv = rv && (ix.tags[r < n ? r : 0] & tag_mask) != 0;
+            }
+            rmask = (uint32_t)__ballot(rv);
+        }
+        for (int g = 0; g < ngroups; g += 2) {
+            load_b(b1, g + 1 < ngroups ? g + 1 : 0);
+            block(araw, b0, g);
+            if (g + 1 < ngroups) {
+                load_b(b0, g + 2 < ngroups ? g + 2 : 0);
+                block(araw, b1, g + 1);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) b0[s] = b1[s];
+            }
+        }
+    };
+    const int64_t W = (int64_t)gridDim.x * K3T_WAVES;
+    const int64_t i0 = (int64_t)blockIdx.x * K3T_WAVES + wave;
+    f32x4 ring[2][4];
+    load_tile(ring[0], i0);
+    for (int64_t i = i0; i < n_sel; i += 2 * W) {
+        load_tile(ring[1], i + W);
+        process(ring[0], i);
+        if (i + W < n_sel) {
+            load_tile(ring[0], i + 2 * W);
+            process(ring[1], i + W);
+        }
     }
+    __builtin_amdgcn_wave_barrier();
+    for (int g = 0; g < ngroups; ++g) {
+        const float m = __builtin_fmaxf(gmax[g * 64 + j], gmax[g * 64 + 32 + j]);
+        if (lane < 32 && m > -__builtin_inff()) atomicMax(&blkmax[32 * g + j], lbh_ord32(m));
+    }
+    __syncthreads();
+    for (int q = tid; q < nq; q += K3T_THREADS) cand3[(size_t)q * BQ_PERQ + blockIdx.x] = (uint64_t)blkmax[q] << 32;
 }
 
 // Per-query seed threshold from the sample pass: (k-th best fp32 score of the sample) - margin.  The
 // sample is a subset of the corpus, so this never exceeds the final cut (global k-th - margin).
-// dense > 0: the list holds exactly `dense` slots written by a DENSE pass (masked rows as 0, which sorts below every score).
+// dense > 0: the list holds exactly `dense` slots written by the SAMPLE pass (one group maximum each; 0, which sorts below
+// every score, for a group without a row that passes the filters).
 __global__ __launch_bounds__(SEL_THREADS) void seed_batched_kernel(int k, float margin, const uint64_t* __restrict__ cand3,
                                                                     int32_t* __restrict__ qtotal,
                                                                     uint32_t* __restrict__ seed, int dense) {
@@ -2167,49 +2251,44 @@ hipError_t lbh_launch_search_noalloc(void* scratch_ptr, const lbh_dev_index& ix,
 static hipError_t launch_batched_tiled(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, int nq, int k, int has_since,
                                        int64_t since_ms, uint64_t tag_mask, int n_cu, float margin, hipStream_t s, hipEvent_t ev0,
                                        hipEvent_t ev1) {
-    hipError_t e = hipMemsetAsync(ws.flags, 0, 16, s);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(ws.bq_total, 0, BQ_MAXQ * BQ_QT * 4, s);
-    if (e != hipSuccess) return e;
+    hipError_t e;
     const f32x4* mat = reinterpret_cast<const f32x4*>(emb16);
     const f32x4* bfrag = reinterpret_cast<const f32x4*>(ws.bq_bfrag);
-    prep_bfrag_kernel<<<8, 256, 0, s>>>(ws.bq_qmat, nq, reinterpret_cast<f16x8*>(ws.bq_bfrag));  // all 8 groups: unused ones as zeros
+    // all 8 groups (unused ones as zeros); also clears the per-query counters and the flag words
+    prep_bfrag_kernel<<<8, 256, 0, s>>>(ws.bq_qmat, nq, reinterpret_cast<f16x8*>(ws.bq_bfrag), ws.bq_total, ws.flags);
     const int64_t T = (ix.n + 31) / 32;
-    auto launch = [&](int64_t n_sel, const uint32_t* seed, bool dense) {
+    auto step_of = [&](int64_t n_sel) -> uint64_t {
         // selected tile i = (i * T) / n_sel in 32.32 fixed point, rounded down so that it never passes T - 1
-        const uint64_t step = n_sel >= T ? (1ull << 32) : (uint64_t)(((unsigned __int128)(uint64_t)T << 32) / (uint64_t)n_sel);
-        if (dense) {
-            scan_batched_dense_kernel<<<dim3((unsigned)((n_sel + 3) / 4)), 256, 0, s>>>(ix, mat, bfrag, nq, has_since, since_ms, tag_mask, T, n_sel,
-                                                                                      step, ws.bq_cand);
-            return;
-        }
+        return n_sel >= T ? (1ull << 32) : (uint64_t)(((unsigned __int128)(uint64_t)T << 32) / (uint64_t)n_sel);
+    };
+    auto launch = [&](int64_t n_sel, const uint32_t* seed) {
         int64_t blocks = (n_sel + K3T_WAVES - 1) / K3T_WAVES;
         if (blocks > K3T_BLOCKS_PER_CU * (int64_t)n_cu) blocks = K3T_BLOCKS_PER_CU * (int64_t)n_cu;
-        scan_batched_tiled_kernel<<<dim3((unsigned)blocks), K3T_THREADS, 0, s>>>(ix, mat, bfrag, nq, has_since, since_ms, tag_mask, T, n_sel, step,
-                                                                                seed, ws.bq_cand, ws.bq_total);
+        scan_batched_tiled_kernel<<<dim3((unsigned)blocks), K3T_THREADS, 0, s>>>(ix, mat, bfrag, nq, has_since, since_ms, tag_mask, T, n_sel,
+                                                                                step_of(n_sel), seed, ws.bq_cand, ws.bq_total);
     };
     if (ev0) (void)hipEventRecord(ev0, s);
     const uint32_t* seed = nullptr;
     if (ix.n > BQ_PERQ) {
-        // growth factor between passes: about k * R rows lie above the k-th best of a 1/R subset; keep that near 2048
-        const double r_max = k >= 512 ? 4.0 : 2048.0 / (double)k;
-        const double ratio = (double)T / (double)K3T_DENSE_TILES;
-        int levels = 1;
-        while (std::pow(r_max, (double)levels) < ratio) ++levels;
-        const double r = std::pow(ratio, 1.0 / (double)levels);
-        launch(K3T_DENSE_TILES, nullptr, true);
-        seed_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(k, margin, ws.bq_cand, ws.bq_total, ws.bq_seed, K3T_DENSE_TILES * 32);
+        // SAMPLE pass over 1/div of the tiles (at least 4096 tiles, or all of them), then thresholds from the group maxima.
+        // About k * div rows per query then reach their threshold in the full pass; the harvest path costs ~0.2 us of a
+        // wave's time per hit, the sample pass its share of a full pass, which puts the optimum near div = 14 at top-8.
+        static const int div = [] {
+            const char* ev = getenv("LBH_BQ_SAMPLE_DIV");
+            const int v = ev ? atoi(ev) : 0;
+            return v >= 1 && v <= 4096 ? v : 14;
+        }();
+        int64_t n_sel = T / div;
+        if (n_sel < 4096) n_sel = T < 4096 ? T : 4096;
+        int64_t blocks = (n_sel + K3T_WAVES - 1) / K3T_WAVES;
+        if (blocks > K3T_BLOCKS_PER_CU * (int64_t)n_cu) blocks = K3T_BLOCKS_PER_CU * (int64_t)n_cu;
+        if (blocks > BQ_PERQ) blocks = BQ_PERQ;  // one list slot per workgroup
+        scan_batched_max_kernel<<<dim3((unsigned)blocks), K3T_THREADS, 0, s>>>(ix, mat, bfrag, nq, has_since, since_ms, tag_mask, T, n_sel,
+                                                                              step_of(n_sel), ws.bq_cand);
+        seed_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(k, margin, ws.bq_cand, ws.bq_total, ws.bq_seed, (int)blocks);
         seed = ws.bq_seed;
-        double sel = (double)K3T_DENSE_TILES;
-        for (int l = 1; l < levels; ++l) {
-            sel *= r;
-            int64_t n_sel = (int64_t)sel;
-            if (n_sel >= T) break;
-            launch(n_sel, seed, false);
-            seed_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(k, margin, ws.bq_cand, ws.bq_total, ws.bq_seed, 0);
-        }
     }
-    launch(T, seed, false);  // seed == nullptr (a corpus that fits the lists): every live row of every query is listed
+    launch(T, seed);  // seed == nullptr (a corpus that fits the lists): every live row of every query is listed
     if (ev1) (void)hipEventRecord(ev1, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -30,4 +30,6 @@ for i, nm in enumerate(names):
     c = t[:, i] - t0
     print(f"  {nm:14s} first {c.min():7.2f}  median {np.median(c):7.2f}  last {c.max():7.2f} us after the first block's start")
 d = np.diff(t, axis=1)
+if os.environ.get("K2_DUMP"):
+    np.save(os.environ["K2_DUMP"], t - t0)
 print("  per-block phase medians (us):", {names[i + 1]: round(float(np.median(d[:, i])), 2) for i in range(5)})
