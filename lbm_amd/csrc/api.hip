@@ -241,6 +241,7 @@ void slot_destroy(lbh_slot* sl) {
         if (ev) (void)hipEventDestroy(ev);
     if (w.result_host) (void)hipHostFree(w.result_host);
     if (w.bq_result_host) (void)hipHostFree(w.bq_result_host);
+    if (w.bq_qhost) (void)hipHostFree(w.bq_qhost);
     if (w.rc_result_host) (void)hipHostFree(w.rc_result_host);
     if (sl->staging) (void)hipHostFree(sl->staging);
     if (sl->own_stream && sl->stream) (void)hipStreamDestroy(sl->stream);
@@ -575,8 +576,11 @@ int ensure_batched_ws(lbh_slot* sl) {
     HIP_TRY(hipMalloc((void**)&w.bq_total, (size_t)LBH_BQ_MAXQ * LBH_BQ_QT_STRIDE * 4));
     HIP_TRY(hipMalloc((void**)&w.bq_seed, (size_t)LBH_BQ_MAXQ * 4));
     HIP_TRY(hipMalloc((void**)&w.bq_bfrag, (size_t)LBH_BQ_MAXQ * 128));
-    HIP_TRY(hipHostMalloc((void**)&w.bq_result_host, sizeof(lbh_result) * LBH_BQ_MAXQ, hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void**)&w.bq_result_host, sizeof(lbh_result) * LBH_BQ_MAXQ, hipHostMallocMapped | hipHostMallocCoherent));
     HIP_TRY(hipHostGetDevicePointer((void**)&w.bq_result_dev, w.bq_result_host, 0));
+    memset(w.bq_result_host, 0, sizeof(lbh_result) * LBH_BQ_MAXQ);
+    HIP_TRY(hipHostMalloc((void**)&w.bq_qhost, (size_t)LBH_BQ_MAXQ * 512, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void**)&w.bq_qhost_dev, w.bq_qhost, 0));
     return LBH_OK;
 }
 
@@ -1207,16 +1211,26 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
             double qn = 0.0;
             for (int q = 0; q < nb; ++q) qn = std::max(qn, vec_norm(q_f64 + (q0 + q) * 64));
             if (!(qn <= 1e15)) return fail(LBH_E_INVALID, "a query vector is not finite (or its norm exceeds 1e15)");
-            HIP_TRY(hipMemcpyAsync(sl->ws.bq_qmat, q_f64 + q0 * 64, (size_t)nb * 512, hipMemcpyHostToDevice, s));
             const float nscale = norm_scale(ix, qn);
             // the fp16 kernel streams the fp16 copy of the matrix (128 B/claim, MFMA-fragment order; built on first use)
             const bool src16 = c->bq_mode == 2 && nscale >= 0.25f && nscale <= 1.001f;
             if (src16 && !emb16_current(ix)) return LBH_NEED_EMB16;
             any16 = any16 || src16;
-            HIP_TRY(lbh_launch_search_batched(dv, src16 ? ix->emb16 : nullptr, sl->ws, nb, (int)keff, has_since, since_ms, tag_mask, c->n_cu, c->bq_mode,
-                                              nscale, s,
-                                              timing ? sl->ev[0] : nullptr, timing ? sl->ev[1] : nullptr));
-            HIP_TRY(hipStreamSynchronize(s));
+            // The queries: the fp16 mode's first kernel reads them straight from device-mapped pinned memory (one host
+            // memcpy, no copy-engine hop, no staging of pageable memory); the other modes take a device copy first.
+            const double* q_src = sl->ws.bq_qmat;
+            if (src16) {
+                memcpy(sl->ws.bq_qhost, q_f64 + q0 * 64, (size_t)nb * 512);
+                q_src = sl->ws.bq_qhost_dev;
+            } else {
+                HIP_TRY(hipMemcpyAsync(sl->ws.bq_qmat, q_f64 + q0 * 64, (size_t)nb * 512, hipMemcpyHostToDevice, s));
+            }
+            const int32_t seq = sl->seq = (sl->seq == INT32_MAX) ? 1 : sl->seq + 1;
+            HIP_TRY(lbh_launch_search_batched(dv, src16 ? ix->emb16 : nullptr, sl->ws, q_src, nb, (int)keff, has_since, since_ms, tag_mask, c->n_cu,
+                                              c->bq_mode, nscale, seq, s, timing ? sl->ev[0] : nullptr, timing ? sl->ev[1] : nullptr));
+            // every query's select block publishes its own ticket into its result block (mapped host memory)
+            for (int i = 0; i < nb; ++i) HIP_TRY(wait_ticket(c, s, &sl->ws.bq_result_host[i].seq, seq));
+            if (timing) HIP_TRY(hipEventSynchronize(sl->ev[1]));
             total.scan_launches += 1;
             total.rows_scanned += ix->n;
             if (timing) {

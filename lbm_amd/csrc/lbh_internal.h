@@ -134,6 +134,8 @@ struct lbh_workspace {
     uint32_t* bq_seed;        // 256 per-query seed thresholds (ord32) from the sample pass
     void* bq_bfrag;           // 32 KiB: the queries as fp16 MFMA B fragments (scan_batched_tiled_kernel)
     lbh_result* bq_result_host;  // 256 results, pinned + device-mapped
+    double* bq_qhost;            // 256 x 64 fp64 queries, pinned + device-mapped (read by the fp16 mode's first kernel)
+    double* bq_qhost_dev;
     lbh_result* bq_result_dev;
     // recency query (get_recent_claims) workspace, allocated on first use
     uint64_t* rc_a;           // LBH_RC_MAX_BLOCKS x LBH_MAX_PAGE candidate keys: created (biased)
@@ -181,9 +183,11 @@ hipError_t lbh_launch_recent(const int64_t* created, const uint64_t* order, int6
                              int page, int has_since, int64_t since_ms, const lbh_rcursor& cur, int64_t anchor_row,
                              int n_cu, int seq, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 // emb16: NULL, or the fp16 copy of the matrix as operand source of the fp16 mode (bf16 == 2)
-hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, int nq, int k, int has_since,
-                                     int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, float norm_scale, hipStream_t s,
-                                     hipEvent_t ev0, hipEvent_t ev1);
+// q_src: where the kernels read the fp64 queries from -- ws.bq_qmat (already copied), or device-mapped host memory (fp16 mode
+// only: its first kernel then leaves the device copy in ws.bq_qmat); seq: completion ticket written into every query's result
+hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, const double* q_src, int nq,
+                                     int k, int has_since, int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, float norm_scale,
+                                     int seq, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 
 // allocation-free search: per-device address of the file-scope scratch array, and the launch sequence on it
 hipError_t lbh_noalloc_init(void** out_ptr);

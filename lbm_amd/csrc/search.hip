@@ -1224,10 +1224,17 @@ constexpr int K3T_STAGE = 256;      // per-wave staging list (entries)
 // B operand image: [group g][k-step s][lane] x 16 B = dims 16 s + 8 h .. + 7 of query 32 g + j as fp16 (one rounding
 // from the fp64 query); queries >= nq are zero
 __global__ void prep_bfrag_kernel(const double* __restrict__ qmat, int nq, f16x8* __restrict__ bfrag, int32_t* __restrict__ qtotal,
-                                  int32_t* __restrict__ flags) {
+                                  int32_t* __restrict__ flags, double* __restrict__ qcopy) {
     if (blockIdx.x == 0) {  // first kernel of a batched search: also clears the per-query counters (no memset launches)
         qtotal[threadIdx.x * BQ_QT] = 0;
         if (threadIdx.x < 4) flags[threadIdx.x] = 0;
+    }
+    if (qcopy) {  // qmat is mapped host memory (no copy-engine hop): leave a device copy for the select kernel's fp64 re-rank
+        const int t = blockIdx.x * 256 + threadIdx.x;  // 2048 threads x 8 doubles = 256 queries x 64
+        if (t * 8 < nq * 64) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qcopy[t * 8 + e] = qmat[t * 8 + e];
+        }
     }
     const int lane = threadIdx.x & 63, s = (threadIdx.x >> 6) & 3, g = blockIdx.x;
     const int j = lane & 31, h = lane >> 5, q = 32 * g + j;
@@ -1389,7 +1396,12 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
         const float m4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
         const float m5 = __builtin_fmaxf(__builtin_fmaxf(m0, m1), m2);
         const float m6 = __builtin_fmaxf(__builtin_fmaxf(m3, m4), acc[15]);
+#ifdef K3T_NOEPI  // timing-only build: what the scan costs without the 16-way maximum
+        const float mx = acc[0];
+        (void)m5; (void)m6;
+#else
         const float mx = __builtin_fmaxf(m5, m6);
+#endif
         const bool lanehit = mx >= thr;
         if (__any(lanehit))  // rare: some query of this group has a row at or above its threshold
             cnt = k3t_harvest(acc, thr, lanehit, 32 * g + j, row0, n, ix.created, ix.tags, has_since, since_ms, tag_mask, se, sq,
@@ -1585,7 +1597,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_batched_kernel(lbh_dev_ind
                                                                       int k, float margin, const uint64_t* __restrict__ cand3,
                                                                       const int32_t* __restrict__ qtotal,
                                                                       const int32_t* __restrict__ flags,
-                                                                      lbh_result* __restrict__ res_arr) {
+                                                                      lbh_result* __restrict__ res_arr, int seq) {
     __shared__ double qs[64];
     const int tid = threadIdx.x, q = blockIdx.x;
     lbh_result* res = res_arr + q;
@@ -1594,11 +1606,13 @@ __global__ __launch_bounds__(SEL_THREADS) void select_batched_kernel(lbh_dev_ind
     const int raw = qtotal[q * BQ_QT];
     if (flags[0] || (raw & BQ_OVER)) {
         if (tid == 0) { res->count = 0; res->overflow = 1; res->candidates = 0; }
+        publish_result(res, seq);
         return;
     }
     int E = raw;
     if (E > BQ_PERQ) E = BQ_PERQ;
     select_fast_body(ix, qs, k, cand3 + (size_t)q * BQ_PERQ, E, res, margin);
+    publish_result(res, seq);  // every query's block carries its own completion ticket (mapped host memory)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2248,14 +2262,15 @@ hipError_t lbh_launch_search_noalloc(void* scratch_ptr, const lbh_dev_index& ix,
 }
 
 // K3, fp16: the pass schedule described above scan_batched_tiled_kernel.
-static hipError_t launch_batched_tiled(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, int nq, int k, int has_since,
-                                       int64_t since_ms, uint64_t tag_mask, int n_cu, float margin, hipStream_t s, hipEvent_t ev0,
-                                       hipEvent_t ev1) {
+static hipError_t launch_batched_tiled(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, const double* q_src, int nq,
+                                       int k, int has_since, int64_t since_ms, uint64_t tag_mask, int n_cu, float margin, int seq,
+                                       hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     hipError_t e;
     const f32x4* mat = reinterpret_cast<const f32x4*>(emb16);
     const f32x4* bfrag = reinterpret_cast<const f32x4*>(ws.bq_bfrag);
     // all 8 groups (unused ones as zeros); also clears the per-query counters and the flag words
-    prep_bfrag_kernel<<<8, 256, 0, s>>>(ws.bq_qmat, nq, reinterpret_cast<f16x8*>(ws.bq_bfrag), ws.bq_total, ws.flags);
+    prep_bfrag_kernel<<<8, 256, 0, s>>>(q_src, nq, reinterpret_cast<f16x8*>(ws.bq_bfrag), ws.bq_total, ws.flags,
+                                        q_src != ws.bq_qmat ? ws.bq_qmat : nullptr);
     const int64_t T = (ix.n + 31) / 32;
     auto step_of = [&](int64_t n_sel) -> uint64_t {
         // selected tile i = (i * T) / n_sel in 32.32 fixed point, rounded down so that it never passes T - 1
@@ -2292,13 +2307,13 @@ static hipError_t launch_batched_tiled(const lbh_dev_index& ix, const uint16_t* 
     if (ev1) (void)hipEventRecord(ev1, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    select_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(ix, ws.bq_qmat, k, margin, ws.bq_cand, ws.bq_total, ws.flags, ws.bq_result_dev);
+    select_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(ix, ws.bq_qmat, k, margin, ws.bq_cand, ws.bq_total, ws.flags, ws.bq_result_dev, seq);
     return hipGetLastError();
 }
 
-hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, int nq, int k, int has_since,
-                                     int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, float norm_scale, hipStream_t s,
-                                     hipEvent_t ev0, hipEvent_t ev1) {
+hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, const double* q_src, int nq,
+                                     int k, int has_since, int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, float norm_scale,
+                                     int seq, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     // one-time set-up (thread-safe: searches on different indexes may arrive concurrently)
     static std::once_flag once;
     static hipError_t once_err = hipSuccess;
@@ -2330,7 +2345,7 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* em
     // components inside its range, so anything but unit-scale data takes the split-bf16 kernel instead (the caller
     // passes the fp16 copy only for unit-scale data)
     if (bf16 == 2 && (!emb16 || norm_scale > 1.001f || norm_scale < 0.25f)) bf16 = 1;
-    if (bf16 == 2) return launch_batched_tiled(ix, emb16, ws, nq, k, has_since, since_ms, tag_mask, n_cu, LBH_MARGIN_F16 * norm_scale, s, ev0, ev1);
+    if (bf16 == 2) return launch_batched_tiled(ix, emb16, ws, q_src, nq, k, has_since, since_ms, tag_mask, n_cu, LBH_MARGIN_F16 * norm_scale, seq, s, ev0, ev1);
     const float margin = (bf16 ? LBH_MARGIN_BF16X3 : LBH_MARGIN) * norm_scale;
     e = hipMemsetAsync(ws.flags, 0, 16, s);
     if (e != hipSuccess) return e;
@@ -2372,7 +2387,7 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* em
     if (ev1) (void)hipEventRecord(ev1, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    select_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(ix, ws.bq_qmat, k, margin, ws.bq_cand, ws.bq_total, ws.flags, ws.bq_result_dev);
+    select_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(ix, ws.bq_qmat, k, margin, ws.bq_cand, ws.bq_total, ws.flags, ws.bq_result_dev, seq);
     return hipGetLastError();
 }
 

@@ -20,14 +20,19 @@ while done < n:
 qv = _hip.embed_batch(synth.make_queries(nq, seed=4321))
 st = _hip.Stats(); st.want_timing = 1
 ix.search(qv, k, _hip.SINCE_NONE, 0, st)
-wall, scan, fb = [], [], 0
+plain = _hip.Stats()  # wall time is taken on calls WITHOUT device events (they add a gap in front of the first scan kernel)
+wall, wall_timed, scan, fb = [], [], [], 0
 for r in range(reps):
     t0 = time.perf_counter()
+    ix.search(qv, k, _hip.SINCE_NONE, 0, plain)
+    wall.append(time.perf_counter() - t0); fb += plain.fallbacks
+    t0 = time.perf_counter()
     ix.search(qv, k, _hip.SINCE_NONE, 0, st)
-    wall.append(time.perf_counter() - t0); scan.append(st.scan_ms / 1e3); fb += st.fallbacks
-w, s = float(np.median(wall)), float(np.median(scan))
+    wall_timed.append(time.perf_counter() - t0); scan.append(st.scan_ms / 1e3); fb += st.fallbacks
+w, wt, s = float(np.median(wall)), float(np.median(wall_timed)), float(np.median(scan))
 flops = 2.0 * 64 * nq * n
+bpc = st.bytes_per_row
 print(json.dumps({"claims": n, "queries": nq, "top_k": k, "path": st.path, "fallbacks": fb,
-                  "wall_ms": w * 1e3, "scan_ms": s * 1e3, "pairs_per_s": n * nq / w,
-                  "scan_tflops": flops / s / 1e12, "frac_of_f32_mfma_peak_157.3": flops / s / 157.3e12,
-                  "scan_GBps": n * 256 / s / 1e9}))
+                  "wall_ms": w * 1e3, "wall_ms_with_event_timing": wt * 1e3, "scan_ms": s * 1e3, "pairs_per_s": n * nq / w,
+                  "scan_tflops": flops / s / 1e12, "frac_of_dense_f16_mfma_peak_2500": flops / s / 2.5e15,
+                  "bytes_per_claim": bpc, "scan_GBps": n * bpc / s / 1e9}))
