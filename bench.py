@@ -231,12 +231,32 @@ def main():
     queries = synth.make_queries(args.queries, seed=4321)
     qvecs = _hip.embed_batch(queries)
     searcher = comm = None
+    exchange_note = ""
     if world > 1 and rehearse:
         searcher = ShardedSearcher(ix.search_shard, rank, world, device=None)
     elif world > 1:
-        uid = [_hip.comm_unique_id() if rank == 0 else None]
+        comm_err = ""
+        try:
+            uid = [_hip.comm_unique_id() if rank == 0 else None]
+        except _hip.HipBackendError as e:  # librccl missing / unusable: every rank learns it through the broadcast
+            uid, comm_err = [b""], str(e)
         dist.broadcast_object_list(uid, src=0)
-        comm = _hip.Comm(uid[0], rank, world)  # collective: RCCL communicator over the node's xGMI links
+        if uid[0]:
+            try:
+                comm = _hip.Comm(uid[0], rank, world)  # collective: RCCL communicator over the node's xGMI links
+            except _hip.HipBackendError as e:
+                comm_err = str(e)
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            # RCCL could not be brought up on every rank: the run still measures the sharded search, with the lists
+            # travelling over gloo instead (said so on the printed line); never silently
+            if comm is not None:
+                comm.close()
+                comm = None
+            exchange_note = "RCCL unavailable (%s): lists gathered over gloo" % (comm_err or "another rank failed")
+            print(f"bench.py rank {rank}: {exchange_note}", file=sys.stderr)
+            searcher = ShardedSearcher(ix.search_shard, rank, world, device=None)
     stats = _hip.Stats()
     every = max(1, args.time_every)
 
@@ -319,7 +339,8 @@ def main():
                                    f"single-query compile_context ranking, top_k={args.top_k}, since_ms={args.since}",
                        "claims_per_gpu": args.claims, "live_claims_total": total_live, "top_k": args.top_k,
                        "parallelism": (f"claim-sharded x{world}, one RCCL all-gather of the per-GPU top-k lists per query (inside liblbhip), "
-                                       "same-comparator merge" if comm is not None else f"claim-sharded x{world}, lists gathered over gloo (rehearsal)")
+                                       "same-comparator merge" if comm is not None else
+                                       f"claim-sharded x{world}, lists gathered over gloo ({exchange_note or 'rehearsal'})")
                        if world > 1 else "single GPU"},
             "latency_ms": {"p50": float(np.percentile(lat, 50) * 1e3), "p99": float(np.percentile(lat, 99) * 1e3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -361,6 +382,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+    if world > 1:
+        dist.barrier()  # no rank tears its communicator down while another may still be inside a collective
     if comm is not None:
         comm.close()
     if world > 1:
