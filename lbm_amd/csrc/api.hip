@@ -1198,7 +1198,9 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
     // K3: three or more queries with a small k share ONE pass over the claim matrix on the matrix
     // cores (256 queries per launch).  A query whose candidate set could not be bounded there is
     // re-run below on the single-query path, so results never depend on which path served them.
-    if (nq >= 3 && keff >= 1 && keff <= LBH_BQ_KMAX && ix->n > 0) {
+    // top_k: the fp16 kernel keeps no per-query state in registers, so it serves any k of one result page (<= 64); the
+    // fp32 / split-bf16 kernels keep k-entry lists per lane and stop at LBH_BQ_KMAX (larger k: single-query path below)
+    if (nq >= 3 && keff >= 1 && keff <= (ix->ctx->bq_mode == 2 ? LBH_MAX_PAGE : LBH_BQ_KMAX) && ix->n > 0) {
         int rc = ensure_batched_ws(sl);
         if (rc) return rc;
         lbh_ctx* c = ix->ctx;
@@ -1214,6 +1216,7 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
             const float nscale = norm_scale(ix, qn);
             // the fp16 kernel streams the fp16 copy of the matrix (128 B/claim, MFMA-fragment order; built on first use)
             const bool src16 = c->bq_mode == 2 && nscale >= 0.25f && nscale <= 1.001f;
+            if (!src16 && keff > LBH_BQ_KMAX) continue;  // data outside fp16's range with a large k: single-query path
             if (src16 && !emb16_current(ix)) return LBH_NEED_EMB16;
             any16 = any16 || src16;
             // The queries: the fp16 mode's first kernel reads them straight from device-mapped pinned memory (one host

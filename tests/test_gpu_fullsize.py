@@ -104,12 +104,13 @@ def test_fast_vs_exact_vs_batched_10m(corpus):
 
 
 def test_batched_256_filters_and_k16_10m(corpus):
-    """Config 3 at full width with the fused masks: 256 queries x 10 M claims, since / tag filters, top-16; every
+    """Config 3 at full width with the fused masks: 256 queries x 10 M claims, since / tag filters, top-16 .. top-64; every
     query equals the single-query path (which test_first_million_against_oracle ties to the oracle)."""
     hip, ix, q = corpus["hip"], corpus["ix"], corpus["q"]
     st = hip.Stats()
     p50 = 1_700_000_000_000 + 1000 * (N_FULL // 2)
-    for k, since, tm in ((16, hip.SINCE_NONE, 0), (8, p50, 0), (8, hip.SINCE_NONE, 0xF0F0), (16, p50, 0x0F0F)):
+    for k, since, tm in ((16, hip.SINCE_NONE, 0), (8, p50, 0), (8, hip.SINCE_NONE, 0xF0F0), (16, p50, 0x0F0F), (64, hip.SINCE_NONE, 0),
+                         (40, p50, 0xFF)):  # k > 16: served by the fp16 kernel only (the default mode)
         bi, bs, bc = ix.search(q, k, since, tm, st)
         assert st.path == 2 and st.bytes_per_row in (128 + 8 * (since != hip.SINCE_NONE) + 8 * (tm != 0),
                                                       256 + 8 * (since != hip.SINCE_NONE) + 8 * (tm != 0))

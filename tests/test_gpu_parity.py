@@ -539,7 +539,8 @@ def test_batched_queries_mfma_path_vs_oracle(hip, bq_mode):
     qv = hip.embed_batch(texts)
     p50 = int(ch.created_ms[ch.n // 2])
     st = hip.Stats()
-    for k, since, tmask in ((8, None, 0), (16, p50, 0), (1, None, 0b110), (8, p50, 1 << 7 | 1)):
+    big_k = ((40, None, 0), (64, p50, 0b1)) if bq_mode == BQ_MODES["fp16"][1] else ()  # k > 16: the fp16 kernel only
+    for k, since, tmask in ((8, None, 0), (16, p50, 0), (1, None, 0b110), (8, p50, 1 << 7 | 1)) + big_k:
         gi, gs, cnt = ix.search(qv, k, hip.SINCE_NONE if since is None else since, tmask, st)
         assert st.path == 2 and st.scan_launches >= 1
         assert 0.0 <= st.max_score_err < bq_mode / 2, st.max_score_err
@@ -549,7 +550,8 @@ def test_batched_queries_mfma_path_vs_oracle(hip, bq_mode):
             n = int(cnt[j])
             assert gi[j, :n].tolist() == want_idx.tolist(), (k, since, tmask, j)
             assert gs[j, :n].tobytes() == want_sc.tobytes(), (k, since, tmask, j)
-        assert st.fallbacks >= 1  # the empty query ties every claim at 0.0 -> served by the exact path
+        if (k, since, tmask) != (64, p50, 0b1):  # (that filter leaves few enough rows for the tied list to fit)
+            assert st.fallbacks >= 1  # the empty query ties every claim at 0.0 -> served by the exact path
     # 300 queries: two launches of the 256-query kernel
     many = synth.make_queries(300, seed=5)
     qm = hip.embed_batch(many)
