@@ -33,6 +33,7 @@ How the mirror works
 """
 from __future__ import annotations
 
+import bisect
 import functools
 import operator
 import re
@@ -63,6 +64,32 @@ def _locked_g(fn):
         with self._g._lock:
             return fn(self, *a, **kw)
     return wrapper
+
+
+_RK_SPACE = 1 << 256  # rank keys are 32-byte integers in (0, 2^256)
+
+
+class _BisectList(list):
+    """The three SortedList operations the rank keys need, on a plain list (inserts move O(N) pointers)."""
+
+    def add(self, v) -> None:
+        bisect.insort_left(self, v)
+
+    def bisect_left(self, v) -> int:
+        return bisect.bisect_left(self, v)
+
+    def remove(self, v) -> None:
+        i = bisect.bisect_left(self, v)
+        if i < len(self) and self[i] == v:
+            del self[i]
+
+
+def _sorted_list(items=()):
+    try:
+        from sortedcontainers import SortedList  # O(log N) inserts; optional
+        return SortedList(items)
+    except ImportError:
+        return _BisectList(sorted(items))
 
 
 _HEX64 = re.compile(r"[0-9a-f]{64}\Z")
@@ -376,6 +403,11 @@ class ContextGraph:
         self._tag_overflow = False
         self._key_mode = "hex"   # "hex" | "raw" | "rank": how claim hashes become 32-byte ordering keys (module docstring)
         self._keys_stale = False
+        # rank-key mode: the hashes that own a device row, in Python's str order, and each one's 256-bit key.  A new hash
+        # takes the midpoint of its neighbours' keys (O(log N) per publish); only a gap that has run out of midpoints --
+        # ~250 inserts at the same spot -- or a change of mode relabels every row.
+        self._rk_order = _sorted_list()
+        self._rk_key: Dict[str, int] = {}
         self._seq_of: Dict[str, int] = {}      # hash -> position stamp in the ``claims`` dict order
         self._next_seq = 0
         self._order_pending: Dict[str, None] = {}  # rows whose stamp is not on the device yet (recency query only)
@@ -428,13 +460,36 @@ class ContextGraph:
                 return bytes.fromhex(h)
             # first hash that is not a CAS hash: an empty device index can still switch to raw keys
             self._key_mode = "raw" if not self._id_of and self._raw_key(h) is not None else "rank"
+            if self._key_mode == "rank" and self._id_of:
+                self._keys_stale = True  # the rows so far carry hex keys
         if self._key_mode == "raw":
             k = self._raw_key(h)
             if k is not None:
                 return k
             self._key_mode = "rank"
-        self._keys_stale = True
-        return b"\x00" * _hip.KEY_BYTES  # placeholder until _refresh_rank_keys
+            self._keys_stale = True  # every row so far carries a key of the old kind
+        return self._rank_key_for(h)
+
+    def _forget_rank_key(self, h: str) -> None:
+        if self._rk_key.pop(h, None) is not None:
+            self._rk_order.remove(h)
+
+    def _rank_key_for(self, h: str) -> bytes:
+        """Rank mode: the key of ``h`` -- its stored one, or a new one between its neighbours in str order."""
+        k = self._rk_key.get(h)
+        if k is None:
+            if self._keys_stale:  # a relabel of every row is pending anyway: placeholder
+                return b"\x00" * _hip.KEY_BYTES
+            i = self._rk_order.bisect_left(h)
+            lo = self._rk_key[self._rk_order[i - 1]] if i > 0 else 0
+            hi = self._rk_key[self._rk_order[i]] if i < len(self._rk_order) else _RK_SPACE
+            k = (lo + hi) // 2
+            if k == lo:  # no room left between the neighbours
+                self._keys_stale = True
+                return b"\x00" * _hip.KEY_BYTES
+            self._rk_order.add(h)
+            self._rk_key[h] = k
+        return k.to_bytes(_hip.KEY_BYTES, "big")
 
     @property
     def _rank_keys(self) -> bool:
@@ -442,13 +497,20 @@ class ContextGraph:
 
     @_locked
     def _refresh_rank_keys(self) -> None:
-        hs = sorted(self._id_of.keys())  # Python str order: what lb/context_graph.py:120 compares
+        """Relabel every row: keys spread evenly over the 256-bit space in Python's str order (what lb/context_graph.py:120
+        compares).  Only on entering rank mode or when a gap between two neighbours is used up."""
+        hs = sorted(self._id_of.keys())
+        self._rk_order = _sorted_list(hs)
+        self._rk_key = {}
         if hs:
+            step = _RK_SPACE // (len(hs) + 1)
             ids = np.array([self._id_of[h] for h in hs], dtype=np.uint64)
-            keys = np.zeros((len(hs), _hip.KEY_BYTES), dtype=np.uint8)
-            ranks = np.arange(len(hs), dtype=">u8")
-            keys[:, :8] = ranks.view(np.uint8).reshape(-1, 8)
-            self._index.set_keys(ids, keys)
+            blob = bytearray()
+            for i, h in enumerate(hs):
+                k = (i + 1) * step
+                self._rk_key[h] = k
+                blob += k.to_bytes(_hip.KEY_BYTES, "big")
+            self._index.set_keys(ids, np.frombuffer(bytes(blob), dtype=np.uint8).reshape(len(hs), _hip.KEY_BYTES))
         self._keys_stale = False
 
     @_locked
@@ -464,6 +526,7 @@ class ContextGraph:
         self._hash_of.pop(cid, None)
         self._meta.pop(h, None)
         self._unscored.pop(h, None)
+        self._forget_rank_key(h)
 
     @_locked
     def _sync(self) -> None:
@@ -519,6 +582,7 @@ class ContextGraph:
                 self._hash_of.pop(self._id_of.pop(h), None)
                 self._meta.pop(h, None)
                 self._unscored.pop(h, None)
+                self._forget_rank_key(h)
         for h in dirty:
             if self._discard.pop(h, 0) is None:
                 self._parked.pop(h, None)
@@ -532,10 +596,7 @@ class ContextGraph:
             if h in self._id_of:
                 cm, tm = int(c.created_ms), self._tagmask(c.tags)
                 if self._meta.get(h) != (cm, tm):
-                    key = self._key_bytes(h) if not self._rank_keys else b"\x00" * _hip.KEY_BYTES
-                    self._index.update_meta(self._id_of[h], cm, tm, key)
-                    if self._rank_keys:
-                        self._keys_stale = True
+                    self._index.update_meta(self._id_of[h], cm, tm, self._key_bytes(h))
                     self._meta[h] = (cm, tm)
                 continue
             if not self._owns(h):  # claim-sharded graph: another rank scans this claim
@@ -565,7 +626,7 @@ class ContextGraph:
             for h, t, _ in new_text:
                 if self._pending_text.pop(h, None) is None:
                     self._unscored[h] = t
-        if self._rank_keys and (self._keys_stale or new_vec or new_text):
+        if self._rank_keys and self._keys_stale:
             self._refresh_rank_keys()
 
     def _register(self, hs: Sequence[str], ids: np.ndarray, created: np.ndarray, tmask: np.ndarray) -> None:

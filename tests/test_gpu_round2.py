@@ -349,6 +349,56 @@ def test_raw_key_mode_and_rank_key_fallback(hip):
         assert g.compile("same text", top_k=20) == og.compile("same text", top_k=20), name
 
 
+def test_rank_keys_are_maintained_incrementally(hip, monkeypatch):
+    """Rank-key mode (hashes that are neither 64-hex nor <= 32 bytes): a publish costs one key between its neighbours in
+    str order, not a re-sort and a rewrite of the key table.  Many exact score ties (identical texts), so the answer is
+    decided by the keys; checked against the oracle graph while claims come and go."""
+    import random
+    from lbm_amd import _hip
+    from lbm_amd.context_graph import ContextGraph
+    calls = []
+    real = _hip.Index.set_keys
+    monkeypatch.setattr(_hip.Index, "set_keys", lambda self, ids, keys: (calls.append(len(ids)), real(self, ids, keys))[1])
+    rnd = random.Random(11)
+    g, og = ContextGraph(), orc.OracleGraph()
+    texts = ["alpha beta", "alpha beta", "alpha beta gamma", "gamma", ""]
+    known = []
+
+    def new_hash():
+        return "".join(rnd.choice("abAB-/~ 0é") for _ in range(rnd.randint(33, 50))) + "#%d" % len(known)
+
+    for step in range(600):
+        r = rnd.random()
+        if r < 0.6 or not known:
+            h = new_hash()
+            known.append(h)
+            t, ms = rnd.choice(texts), rnd.randint(0, 9)
+            g.add_claim(h, t, [], created_ms=ms); og.add_claim(h, t, [], created_ms=ms)
+        elif r < 0.75:
+            h = rnd.choice(known)
+            g.retract(h); og.retract(h)
+        elif r < 0.8:
+            h = rnd.choice(known)
+            if h in og.claims:
+                g.claims[h].created_ms = 5; og.claims[h].created_ms = 5
+        else:
+            kw = {"top_k": rnd.choice([1, 8, 30, 100])}
+            if rnd.random() < 0.3:
+                kw["since_ms"] = rnd.randint(0, 9)
+            q = rnd.choice(["alpha", "gamma beta", ""])
+            assert g.compile(q, **kw) == og.compile(q, **kw), (step, q, kw)
+    assert g._key_mode == "rank"
+    assert calls == [], calls  # an empty graph enters rank mode without a relabel; every publish placed its own key
+    # a gap that runs out of midpoints triggers one relabel and nothing else changes
+    base = "m" * 40
+    for i in range(300):
+        h = base + "m" * (i + 1)
+        g.add_claim(h, "alpha beta", [], created_ms=1); og.add_claim(h, "alpha beta", [], created_ms=1)
+        if i % 50 == 49:
+            assert g.compile("alpha", top_k=64) == og.compile("alpha", top_k=64), i
+    assert 1 <= len(calls) <= 3, calls
+
+
 def test_group_graph_save_load_and_rebuild(hip, tmp_path, golden_snapshot):
     """lb/group.py:30-55 (graph half) and lb/node.py:486-515: graph.json round trip and the rebuild from a resolved
     transaction stream, both ending in one bulk K1 launch, against the reference's reloaded-graph results."""
