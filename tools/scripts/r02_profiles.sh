@@ -21,4 +21,9 @@ step k3fetch; timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_k3_fetch 
 step k3write; timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_k3_write -o w --output-format csv -- $B > $O/pmc_k3_write.log 2>&1
 step k3trace; timeout -k 10 200 rocprofv3 --kernel-trace -d $O/r02_k3_trace -o k3 --output-format csv -- $B > $O/r02_k3_trace.log 2>&1
 find $O -name '*_agent_info.csv' -delete
-echo done
+echo profiles done
+cd $R
+echo "== configs"; timeout -k 10 900 python3 tools/run_configs.py > $O/r02_configs.json 2> $O/r02_configs.err
+echo "== sharded overhead"; timeout -k 10 300 python3 tools/sharded_overhead.py > $O/r02_sharded_overhead.json 2> $O/r02_sharded_overhead.err
+echo "== concurrent"; timeout -k 10 200 python3 tools/concurrent_search.py 1000000 2000 > $O/r02_concurrent_1m.json 2> $O/r02_concurrent_1m.err
+echo all done
