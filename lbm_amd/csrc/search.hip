@@ -1207,8 +1207,11 @@ __global__ __launch_bounds__(BQ_THREADS) void scan_batched_kernel(lbh_dev_index 
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#ifndef K3T_BREG
+#define K3T_BREG 1                  // 1: all eight query groups' B fragments in registers (2 waves per SIMD); 0: re-read from LDS (4 waves)
+#endif
 #ifndef K3T_THREADS
-#define K3T_THREADS 512             // workgroup of the scan kernel (its waves share the LDS image of the queries)
+#define K3T_THREADS (K3T_BREG ? 256 : 512)  // workgroup of the full-pass kernel
 #endif
 #ifndef K3T_BLOCKS_PER_CU
 #define K3T_BLOCKS_PER_CU 2
@@ -1218,6 +1221,11 @@ constexpr int K3T_STAGE = 256;      // per-wave staging list (entries)
 #ifndef K3T_RING
 #define K3T_RING 2                  // claim tiles in flight per wave (register sets of 16 VGPRs)
 #endif
+// the sample pass (scan_batched_max_kernel) keeps the LDS variant's shape: ~104 registers, 4 waves per SIMD
+#define K3M_THREADS 512
+#define K3M_BLOCKS_PER_CU 2
+constexpr int K3M_WAVES = K3M_THREADS / 64;
+#define K3M_WPS (K3M_BLOCKS_PER_CU * K3M_THREADS / 256)
 #define K3T_WPS (K3T_BLOCKS_PER_CU * K3T_THREADS / 256)  // waves per SIMD the register budget is sized for
 
 
@@ -1322,19 +1330,33 @@ int k3t_harvest(f32x16 acc, float thr, bool lanehit, int q, int64_t row0, int64_
     return cnt;
 }
 
-// The scan kernel.  Workgroup = K3T_THREADS threads; its waves share one read-only LDS image of the queries (B fragments
-// of all groups, 32 KiB, plus the 256 thresholds) filled once in the prologue -- the only barrier of the kernel.  Keeping
+// The scan kernel.  Two builds of the B operand (K3T_BREG):
+//  1 (default): every wave keeps the B fragments of all eight query groups in registers for the whole launch (128 of its
+//    ~250 VGPRs, two waves per SIMD, 256-thread workgroups); no LDS traffic in the loop, the group loop is fully unrolled.
+//    5-6 % faster than (0) on the same box (10 M x 256: scan kernels 0.392 vs 0.416 ms) -- the microbenchmark of the block
+//    pattern (tools/mfma_block_rate.hip) gives 23.3 ns per MFMA at two waves with B in registers against 27.8 ns at four
+//    waves with B from LDS.  A third tile in flight (ring of 3) spills 12 registers and gives the gain back.
+//  0: the waves of a 512-thread workgroup share one read-only LDS image of the queries (B fragments of all groups,
+//    32 KiB) filled once in the prologue, four waves per SIMD.  The notes below are from this variant's development.
+// Both keep the 256 thresholds in LDS; the prologue's barrier is the only one of the kernel.  Keeping
 // the 128 VGPRs of B fragments in registers instead left room for two waves per SIMD at best, with spills next to the
 // tile ring; a wave alone on its SIMD cannot issue the epilogue's vector instructions fast enough (4 cycles each instead
 // of 2) and, with the accumulators in AGPRs, needs 16 extra moves per block (measured: 456-490 us for the full pass
 // against 379 us at two waves per SIMD).  From LDS a group's B fragments cost four conflict-free ds_read_b128 per 32 x 32
 // block (a third of the LDS bandwidth when the matrix pipes are saturated), are prefetched one group ahead, and a wave
 // needs ~110 registers, so K3T_WPS waves per SIMD overlap one wave's MFMAs with the others' epilogues and loads.
+#if K3T_BREG
+#define K3T_LDSB bfrag
+#else
+#define K3T_LDSB ldsb
+#endif
 __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kernel(
     lbh_dev_index ix, const f32x4* __restrict__ emb16t, const f32x4* __restrict__ bfrag, int nq, int has_since, int64_t since_ms,
     uint64_t tag_mask, int64_t n_tiles, int64_t n_sel, uint64_t step_q32, const uint32_t* __restrict__ seed,
     uint64_t* __restrict__ cand3, int32_t* __restrict__ qtotal) {
+#if !K3T_BREG
     __shared__ f32x4 ldsb[8 * 4 * 64];  // [group][k-step][lane] x 16 B
+#endif
     __shared__ float ldsthr[BQ_MAXQ];
     __shared__ uint64_t stage_e[K3T_WAVES][K3T_STAGE];
     __shared__ uint16_t stage_q[K3T_WAVES][K3T_STAGE];
@@ -1346,7 +1368,9 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
     uint16_t* sq = stage_q[wave];
     int cnt = 0;
 
+#if !K3T_BREG
     for (int i = tid; i < ngroups * 256; i += K3T_THREADS) ldsb[i] = bfrag[i];
+#endif
     for (int q = tid; q < BQ_MAXQ; q += K3T_THREADS) {
         const uint32_t o = (seed && q < nq) ? seed[q] : 0u;
         ldsthr[q] = q < nq ? (o ? lbh_unord32(o) : -__builtin_inff()) : __builtin_inff();
@@ -1371,11 +1395,11 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
 #pragma unroll
         for (int s = 0; s < 4; ++s) a[s] = __builtin_nontemporal_load(p + s * 64);
     };
-    auto load_b_lds = [&](f32x4 (&b)[4], int g) {
+    auto load_b_lds = [&](f32x4 (&b)[4], int g) {  // K3T_BREG: once per launch, straight from the global image
 #pragma unroll
-        for (int s = 0; s < 4; ++s) b[s] = ldsb[(g * 4 + s) * 64 + lane];
+        for (int s = 0; s < 4; ++s) b[s] = K3T_BREG ? bfrag[(g * 4 + s) * 64 + lane] : K3T_LDSB[(g * 4 + s) * 64 + lane];
     };
-    auto load_b = [&](f32x4 (&b)[4], int g) {
+    [[maybe_unused]] auto load_b = [&](f32x4 (&b)[4], int g) {
 #ifndef K3T_NOBREAD  // timing-only build: the B fragments are read once (what the scan costs without the LDS traffic)
         load_b_lds(b, g);
 #endif
@@ -1413,6 +1437,17 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
 
     // one tile against every query group; the next group's B fragments are read from LDS while this group's MFMAs run
     // (two register sets, ping-pong; after the last group the prefetch wraps to group 0 for the next tile)
+#if K3T_BREG  // experiment: all eight groups' B fragments in registers (128 VGPRs), two waves per SIMD, no LDS reads in the loop
+    f32x4 breg[8][4];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) load_b_lds(breg[g], g < ngroups ? g : 0);
+    auto process = [&](const f32x4 (&araw)[4], int64_t i) {
+        const int64_t row0 = tile_of(i) * 32;
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            if (g < ngroups) block(araw, breg[g], g, row0);  // wave-uniform
+    };
+#else
     f32x4 b0[4], b1[4];
     load_b_lds(b0, 0);
 #ifdef K3T_NOBREAD
@@ -1432,6 +1467,7 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
             }
         }
     };
+#endif
 
     // K3T_RING claim tiles in flight per wave.  The ring loop is fully unrolled, so every register set has a static name
     // (rotating the sets with register moves would make each move wait for the youngest load).
@@ -1457,19 +1493,19 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
 // and the workgroup writes ONE value per query -- slot blockIdx.x of the query's list, in the list's entry format, 0 when
 // no row of the group passes the filters -- for seed_batched_kernel to pick the k-th largest of.  Scores come out of the
 // same instruction sequence on the same operands as in the full pass, hence bit-identical.
-__global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_max_kernel(
+__global__ __launch_bounds__(K3M_THREADS, K3M_WPS) void scan_batched_max_kernel(
     lbh_dev_index ix, const f32x4* __restrict__ emb16t, const f32x4* __restrict__ bfrag, int nq, int has_since, int64_t since_ms,
     uint64_t tag_mask, int64_t n_tiles, int64_t n_sel, uint64_t step_q32, uint64_t* __restrict__ cand3) {
     __shared__ f32x4 ldsb[8 * 4 * 64];
     __shared__ uint32_t blkmax[BQ_MAXQ];
-    __shared__ float wmax[K3T_WAVES][8 * 64];
+    __shared__ float wmax[K3M_WAVES][8 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int ngroups = (nq + 31) >> 5;
     const int64_t n = ix.n;
     const bool filtered = has_since || tag_mask;
-    for (int i = tid; i < ngroups * 256; i += K3T_THREADS) ldsb[i] = bfrag[i];
-    for (int q = tid; q < BQ_MAXQ; q += K3T_THREADS) blkmax[q] = 0u;
+    for (int i = tid; i < ngroups * 256; i += K3M_THREADS) ldsb[i] = bfrag[i];
+    for (int q = tid; q < BQ_MAXQ; q += K3M_THREADS) blkmax[q] = 0u;
     __syncthreads();
     auto tile_of = [&](int64_t i) -> int64_t {
         const int64_t t = (int64_t)(((unsigned __int128)(uint64_t)i * step_q32) >> 32);
@@ -1540,8 +1576,8 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_max_kernel(
             }
         }
     };
-    const int64_t W = (int64_t)gridDim.x * K3T_WAVES;
-    const int64_t i0 = (int64_t)blockIdx.x * K3T_WAVES + wave;
+    const int64_t W = (int64_t)gridDim.x * K3M_WAVES;
+    const int64_t i0 = (int64_t)blockIdx.x * K3M_WAVES + wave;
     f32x4 ring[2][4];
     load_tile(ring[0], i0);
     for (int64_t i = i0; i < n_sel; i += 2 * W) {
@@ -1558,7 +1594,7 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_max_kernel(
         if (lane < 32 && m > -__builtin_inff()) atomicMax(&blkmax[32 * g + j], lbh_ord32(m));
     }
     __syncthreads();
-    for (int q = tid; q < nq; q += K3T_THREADS) cand3[(size_t)q * BQ_PERQ + blockIdx.x] = (uint64_t)blkmax[q] << 32;
+    for (int q = tid; q < nq; q += K3M_THREADS) cand3[(size_t)q * BQ_PERQ + blockIdx.x] = (uint64_t)blkmax[q] << 32;
 }
 
 // Per-query seed threshold from the sample pass: (k-th best fp32 score of the sample) - margin.  The
@@ -2295,10 +2331,10 @@ static hipError_t launch_batched_tiled(const lbh_dev_index& ix, const uint16_t* 
         }();
         int64_t n_sel = T / div;
         if (n_sel < 4096) n_sel = T < 4096 ? T : 4096;
-        int64_t blocks = (n_sel + K3T_WAVES - 1) / K3T_WAVES;
-        if (blocks > K3T_BLOCKS_PER_CU * (int64_t)n_cu) blocks = K3T_BLOCKS_PER_CU * (int64_t)n_cu;
+        int64_t blocks = (n_sel + K3M_WAVES - 1) / K3M_WAVES;
+        if (blocks > K3M_BLOCKS_PER_CU * (int64_t)n_cu) blocks = K3M_BLOCKS_PER_CU * (int64_t)n_cu;
         if (blocks > BQ_PERQ) blocks = BQ_PERQ;  // one list slot per workgroup
-        scan_batched_max_kernel<<<dim3((unsigned)blocks), K3T_THREADS, 0, s>>>(ix, mat, bfrag, nq, has_since, since_ms, tag_mask, T, n_sel,
+        scan_batched_max_kernel<<<dim3((unsigned)blocks), K3M_THREADS, 0, s>>>(ix, mat, bfrag, nq, has_since, since_ms, tag_mask, T, n_sel,
                                                                               step_of(n_sel), ws.bq_cand);
         seed_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(k, margin, ws.bq_cand, ws.bq_total, ws.bq_seed, (int)blocks);
         seed = ws.bq_seed;
