@@ -1336,6 +1336,8 @@ int k3t_harvest(f32x16 acc, float thr, bool lanehit, int q, int64_t row0, int64_
 //    5-6 % faster than (0) on the same box (10 M x 256: scan kernels 0.392 vs 0.416 ms) -- the microbenchmark of the block
 //    pattern (tools/mfma_block_rate.hip) gives 23.3 ns per MFMA at two waves with B in registers against 27.8 ns at four
 //    waves with B from LDS.  A third tile in flight (ring of 3) spills 12 registers and gives the gain back.
+//    Touching the tile after next with one dword per lane, to pull it into L2 a tile-time early with a single extra
+//    register, made the pass 4 % slower (0.403 -> 0.42 ms of scan kernels): the extra requests cost more than they hide.
 //  0: the waves of a 512-thread workgroup share one read-only LDS image of the queries (B fragments of all groups,
 //    32 KiB) filled once in the prologue, four waves per SIMD.  The notes below are from this variant's development.
 // Both keep the 256 thresholds in LDS; the prologue's barrier is the only one of the kernel.  Keeping
