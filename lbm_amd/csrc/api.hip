@@ -69,7 +69,7 @@ struct lbh_ctx {
     int64_t d_vec_cap = 0;
 };
 
-#define LBH_SLOTS 2  // searches that may run on one index at the same time (each has its own workspace and stream)
+#define LBH_SLOTS 4  // searches that may run on one index at the same time (each has its own workspace and stream)
 
 // Everything ONE search in flight needs besides the index's arrays: workspace, result block, query, events, stream.
 struct lbh_slot {
