@@ -13,7 +13,12 @@
  *     little-endian.  Pointers are HOST pointers unless the name ends in _dev.
  *   - handles are released only through lbh_shutdown / lbh_index_destroy.
  *   - one context = one GPU (one process per GPU); an index belongs to the
- *     context that created it.  Calls on one index are serialised internally.
+ *     context that created it.  Any thread may call: searches (lbh_index_search*,
+ *     lbh_index_recent, lbh_index_size) on one index run concurrently -- up to four
+ *     at a time, further ones wait -- while add / retract / metadata edits are
+ *     exclusive (the reference's compile_context takes no lock, its writers hold
+ *     BatteryNode._lock: lb/node.py:718 vs :450).  lbh_index_search_sharded is a
+ *     collective: one at a time per communicator, in the same order on every rank.
  *   - there is NO CPU fallback: without a usable gfx950 device lbh_init fails.
  */
 #ifndef LBHIP_H
@@ -150,7 +155,10 @@ int lbh_index_get_embeddings(lbh_index* idx, int64_t n, const uint64_t* ids, dou
  *   tag_mask  0 = no tag filter (reference behaviour); else rows need (tagmask & tag_mask) != 0
  * Outputs, per query q: out_counts[q] results in out_ids[q*k ..] / out_scores[q*k ..], ordered
  * exactly like the reference: score descending, then hash key ascending.  Scores are the
- * reference's fp64 values bit-for-bit.  stats may be NULL. */
+ * reference's fp64 values bit-for-bit.  stats may be NULL.
+ * Three or more queries with 1 <= k <= 64 (<= 16 unless the scan runs in its default fp16 mode on
+ * unit-scale vectors) share ONE pass over the claim matrix on the matrix cores, 256 queries per
+ * launch; results do not depend on which path served a query. */
 int lbh_index_search(lbh_index* idx, const double* q_f64, int64_t nq, int64_t k, int64_t since_ms,
                      uint64_t tag_mask, uint64_t* out_ids, double* out_scores, int64_t* out_counts,
                      lbh_stats* stats);

@@ -570,16 +570,18 @@ int search_loaded(lbh_index* ix, lbh_slot* sl, int64_t k, int64_t since_ms, uint
 
 int ensure_batched_ws(lbh_slot* sl) {
     lbh_workspace& w = sl->ws;
-    if (w.bq_qmat) return LBH_OK;
-    HIP_TRY(hipMalloc((void**)&w.bq_qmat, (size_t)LBH_BQ_MAXQ * 512));
-    HIP_TRY(hipMalloc((void**)&w.bq_cand, (size_t)LBH_BQ_MAXQ * LBH_BQ_PERQ * 8));
-    HIP_TRY(hipMalloc((void**)&w.bq_total, (size_t)LBH_BQ_MAXQ * LBH_BQ_QT_STRIDE * 4));
-    HIP_TRY(hipMalloc((void**)&w.bq_seed, (size_t)LBH_BQ_MAXQ * 4));
-    HIP_TRY(hipMalloc((void**)&w.bq_bfrag, (size_t)LBH_BQ_MAXQ * 128));
-    HIP_TRY(hipHostMalloc((void**)&w.bq_result_host, sizeof(lbh_result) * LBH_BQ_MAXQ, hipHostMallocMapped | hipHostMallocCoherent));
+    if (w.bq_qhost_dev) return LBH_OK;  // the last pointer set: a call that failed half-way is completed by the next one
+    if (!w.bq_qmat) HIP_TRY(hipMalloc((void**)&w.bq_qmat, (size_t)LBH_BQ_MAXQ * 512));
+    if (!w.bq_cand) HIP_TRY(hipMalloc((void**)&w.bq_cand, (size_t)LBH_BQ_MAXQ * LBH_BQ_PERQ * 8));
+    if (!w.bq_total) HIP_TRY(hipMalloc((void**)&w.bq_total, (size_t)LBH_BQ_MAXQ * LBH_BQ_QT_STRIDE * 4));
+    if (!w.bq_seed) HIP_TRY(hipMalloc((void**)&w.bq_seed, (size_t)LBH_BQ_MAXQ * 4));
+    if (!w.bq_bfrag) HIP_TRY(hipMalloc((void**)&w.bq_bfrag, (size_t)LBH_BQ_MAXQ * 128));
+    if (!w.bq_result_host) {
+        HIP_TRY(hipHostMalloc((void**)&w.bq_result_host, sizeof(lbh_result) * LBH_BQ_MAXQ, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(w.bq_result_host, 0, sizeof(lbh_result) * LBH_BQ_MAXQ);
+    }
     HIP_TRY(hipHostGetDevicePointer((void**)&w.bq_result_dev, w.bq_result_host, 0));
-    memset(w.bq_result_host, 0, sizeof(lbh_result) * LBH_BQ_MAXQ);
-    HIP_TRY(hipHostMalloc((void**)&w.bq_qhost, (size_t)LBH_BQ_MAXQ * 512, hipHostMallocMapped));
+    if (!w.bq_qhost) HIP_TRY(hipHostMalloc((void**)&w.bq_qhost, (size_t)LBH_BQ_MAXQ * 512, hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer((void**)&w.bq_qhost_dev, w.bq_qhost, 0));
     return LBH_OK;
 }
