@@ -76,7 +76,7 @@ int lbh_version(void);
 /* Name of the device the context runs on, e.g. "gfx950:sramecc+:xnack-". */
 int lbh_device_name(lbh_ctx* ctx, char* buf, int buflen);
 
-/* Tuning knobs (no reference counterpart).  name: "scan_blocks_per_cu" (1..8, default 2),
+/* Tuning knobs (no reference counterpart).  name: "scan_blocks_per_cu" (1..8; 0 = by index size, the default),
  * "scan_nt" (0/1: non-temporal loads in the single-query scan), "scan_mode" (0 = scan the fp32
  * matrix, 256 B/claim, default; 1 = scan a 128 B/claim fp16 copy that the index builds on first
  * use, wider candidate margin, unit-scale data only - results are the same either way, the

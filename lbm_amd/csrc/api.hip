@@ -51,7 +51,7 @@ struct lbh_ctx {
     hipStream_t copy_stream = nullptr;            // H2D copies of lbh_index_add's text slices (overlap with K1 on `stream`)
     hipEvent_t copy_ev[LBH_ADD_SLICES] = {};
     std::string arch;
-    int scan_blocks_per_cu = 2;  // tuning knobs (env LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT), see DESIGN.md
+    int scan_blocks_per_cu = 0;  // tuning knobs (env LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT); 0 = by index size (lbh_scan_grid)
     int scan_nt = 1;
     int scan_mode = 0;   // single-query scan: 0 = fp32 matrix (256 B/claim), 1 = fp16 copy (128 B/claim, margin 2.2e-3; opt-in)
     int bq_mode = 2;     // batched scan: 0 = exact fp32 MFMA, 1 = split-bf16 products (3 MFMAs at 16x the fp32 rate),
@@ -639,7 +639,7 @@ int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx) {
     c->device = devices[0];
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->arch = prop.gcnArchName;
-    if (const char* e1 = getenv("LBH_SCAN_BLOCKS_PER_CU")) c->scan_blocks_per_cu = std::max(1, std::min(8, atoi(e1)));
+    if (const char* e1 = getenv("LBH_SCAN_BLOCKS_PER_CU")) c->scan_blocks_per_cu = std::max(0, std::min(8, atoi(e1)));
     if (const char* e2 = getenv("LBH_SCAN_NT")) c->scan_nt = atoi(e2) != 0;
     if (const char* e5 = getenv("LBH_SCAN_MODE")) c->scan_mode = atoi(e5) != 0;
     if (const char* e4 = getenv("LBH_BQ_MODE")) c->bq_mode = std::max(0, std::min(2, atoi(e4)));
@@ -684,7 +684,7 @@ int lbh_device_name(lbh_ctx* c, char* buf, int buflen) {
 int lbh_set_option(lbh_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return fail(LBH_E_INVALID, "bad argument");
     std::lock_guard<std::mutex> lk(c->mu);
-    if (!strcmp(name, "scan_blocks_per_cu")) c->scan_blocks_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(8, value));
+    if (!strcmp(name, "scan_blocks_per_cu")) c->scan_blocks_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(8, value));
     else if (!strcmp(name, "scan_nt")) c->scan_nt = value != 0;
     else if (!strcmp(name, "scan_mode")) c->scan_mode = value != 0;
     else if (!strcmp(name, "bq_mode")) c->bq_mode = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));

@@ -7,7 +7,9 @@
 #include "../../include/lbhip.h"
 
 #define LBH_WAVE 64
+#ifndef LBH_SCAN_THREADS
 #define LBH_SCAN_THREADS 256                    // 4 waves per scan block
+#endif
 #define LBH_SCAN_WAVES (LBH_SCAN_THREADS / 64)
 #define LBH_WCAP 256                            // per-wave candidate buffer (entries) in LDS
 #define LBH_LIST_CAP 256                        // per-block candidate list written to HBM

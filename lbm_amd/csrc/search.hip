@@ -2139,6 +2139,11 @@ hipError_t lbh_launch_recent(const int64_t* created, const uint64_t* order, int6
 }
 
 int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu) {
+    // blocks_per_cu <= 0: by size.  Up to ~2 M rows ONE 4-wave block per CU is faster (1 M rows: scan 56 -> 50 us, 300 k:
+    // 24.8 -> 23.2, 100 k: 16.2 -> 14.4): half as many block epilogues and candidate lists, and the streaming loop has too
+    // few tiles per wave for a second block to hide anything.  From ~3 M rows on two blocks per CU win by 1-3 %
+    // (tools/scripts/scan_block_sweep.sh; 512-thread blocks were measured too: within noise of these two).
+    if (blocks_per_cu <= 0) blocks_per_cu = n_rows <= 2000000 ? 1 : 2;
     const int64_t tiles = (n_rows + 63) / 64;
     int64_t blocks = (tiles + LBH_SCAN_WAVES - 1) / LBH_SCAN_WAVES;
     const int64_t cap = (int64_t)n_cu * blocks_per_cu < LBH_MAX_BLOCKS ? (int64_t)n_cu * blocks_per_cu : LBH_MAX_BLOCKS;
@@ -2232,7 +2237,9 @@ constexpr size_t NA_OFF_XROW = NA_OFF_XORD + (size_t)NA_EXACT_BLOCKS * LBH_SCAN_
 constexpr size_t NA_OFF_FLAGS = NA_OFF_XROW + (size_t)NA_EXACT_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 4;     // + 128 KiB
 constexpr size_t NA_OFF_RESULT = NA_OFF_FLAGS + 512;
 constexpr size_t NA_BYTES = NA_OFF_RESULT + ((sizeof(lbh_result) + 255) / 256) * 256;
+#ifndef LBH_EXPERIMENT
 static_assert(NA_BYTES == LBH_NOALLOC_SCRATCH_BYTES, "include/lbhip.h states the size of the scratch array");
+#endif
 
 static __device__ __align__(256) unsigned char scratch[NA_BYTES];
 
@@ -2266,7 +2273,7 @@ hipError_t lbh_launch_search_noalloc(void* scratch_ptr, const lbh_dev_index& ix,
     // the array keeps the last call's contents: counters and the result header must start at zero
     hipError_t e = hipMemsetAsync(flags, 0, 512 + 64, s);
     if (e != hipSuccess) return e;
-    int grid = lbh_scan_grid(ix.n, n_cu, 2);
+    int grid = lbh_scan_grid(ix.n, n_cu, 0);
     if (grid > NA_FAST_BLOCKS) grid = NA_FAST_BLOCKS;
     const dim3 g(grid), b(LBH_SCAN_THREADS);
 #define LBH_NA_ARGS ix, nullptr, nullptr, qa, k, margin, since_ms, tag_mask, cand, flags

@@ -20,7 +20,7 @@ for s in range(0, n, chunk):
 qs = rng.standard_normal((16, 64)); qs /= np.linalg.norm(qs, axis=1, keepdims=True)
 st = _hip.Stats(); st.want_timing = 2
 _hip.set_option("scan_mode", mode)
-configs = [(b, nt) for b in (2, 3, 4, 5, 6, 8) for nt in (0, 1)]
+configs = [(b, nt) for b in (1, 2, 3, 4, 5, 6, 8) for nt in (0, 1)]
 res = {c: [] for c in configs}; tot = {c: [] for c in configs}
 for rnd in range(6):
     for c in configs:
