@@ -176,3 +176,41 @@ def test_graph_compile_from_threads_while_a_publisher_adds_and_retracts(hip, gol
 
     _run_threads([publisher, readers_then_stop])
     assert done and done[0] > 0
+
+
+@pytest.mark.timeout(300)
+def test_more_searching_threads_than_slots(hip):
+    """Eight threads on one index: more than the library has per-search workspaces (four), so some wait for a slot; every
+    answer equals the single-threaded one, and a batched search, a recency query and an append slip in between."""
+    rng = np.random.default_rng(5)
+    n = 200_000
+    v = rng.standard_normal((n, 64))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    ix = hip.Index()
+    ix.add_vectors(v, np.arange(n, dtype=np.int64), None, rng.integers(0, 256, size=(n, 32), dtype=np.uint8))
+    qs = rng.standard_normal((32, 64))
+    qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+    want = [tuple(x.tobytes() for x in ix.search_shard(qs[j], 8)[:2]) for j in range(32)]
+    want_b = ix.search(qs, 8)
+    counts = [0] * 8
+
+    def worker(t):
+        def run():
+            for r in range(120):
+                j = (r * 3 + t) % 32
+                got = ix.search_shard(qs[j], 8)
+                assert (got[0].tobytes(), got[1].tobytes()) == want[j], (t, r)
+                if t == 0 and r % 40 == 7:
+                    gi, gs, gc = ix.search(qs, 8)
+                    assert gi.tobytes() == want_b[0].tobytes() and gs.tobytes() == want_b[1].tobytes()
+                if t == 1 and r % 40 == 9:
+                    assert len(ix.recent(n - 10, 64)[0]) == 10
+                if t == 2 and r % 40 == 11:  # a zero vector never enters a top-8 whose scores are positive
+                    ix.retract_many(ix.add_vectors(np.zeros((3, 64)), np.zeros(3, dtype=np.int64), None,
+                                                   rng.integers(0, 256, size=(3, 32), dtype=np.uint8)))
+                counts[t] += 1
+        return run
+
+    _run_threads([worker(t) for t in range(8)])
+    assert counts == [120] * 8 and ix.size() == n
+    ix.close()
