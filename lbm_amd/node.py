@@ -48,6 +48,37 @@ class Group:
         return Group(group_id)
 
 
+def _claim_fields(obj: Dict[str, Any]) -> Dict[str, Any]:
+    """Keyword arguments of ``add_claim`` from a stored claim object, with the reference's defaults and coercions
+    (lb/node.py:499-506: missing text -> "", missing lists -> [], created_ms None / missing -> 0)."""
+    created = obj.get("created_ms", 0)
+    return {"text": str(obj.get("text", "")),
+            "tags": list(obj.get("tags", [])),
+            "evidence": list(obj.get("evidence", [])),
+            "created_ms": int(created) if created else 0,
+            "parent_hash": obj.get("parent_hash")}
+
+
+def _replay_ops(txs: Iterable[Dict[str, Any]]):
+    """(op, claim_hash, add_claim fields | None) for every transaction that changes a graph, in stream order.  Anything
+    malformed is skipped, as the reference skips a claim it cannot rebuild (it logs and continues, lb/node.py:507-509)."""
+    for tx in txs:
+        kind = tx.get("type")
+        if kind == "retract":
+            target = tx.get("claim_hash")
+            if isinstance(target, str):
+                yield "retract", target, None
+        elif kind == "claim":
+            claim_hash, obj = tx.get("artifact_hash"), tx.get("object")
+            if not (isinstance(claim_hash, str) and isinstance(obj, dict)):
+                continue
+            try:
+                fields = _claim_fields(obj)
+            except (TypeError, ValueError):
+                continue
+            yield "claim", claim_hash, fields
+
+
 class RetrievalNode:
     def __init__(self) -> None:
         self.groups: Dict[str, Group] = {}
@@ -78,30 +109,14 @@ class RetrievalNode:
         ``cas.get_json(h)`` returns; a missing / non-dict object skips the claim like a CAS miss does) and
         ``{"type": "retract", "claim_hash": h}``.  A NEW graph replaces the group's, exactly as in the reference; every
         claim it keeps is vectorised in one K1 launch at the first query and the retracts never reach the device."""
-        g = self._require_group(group_id)
-        new_graph = ContextGraph()
-        for tx in txs:
-            t = tx.get("type")
-            if t == "claim":
-                h = tx.get("artifact_hash")
-                obj = tx.get("object")
-                if isinstance(h, str) and isinstance(obj, dict):
-                    try:
-                        new_graph.add_claim(
-                            h,
-                            text=str(obj.get("text", "")),
-                            tags=list(obj.get("tags", [])),
-                            evidence=list(obj.get("evidence", [])),
-                            created_ms=int(obj.get("created_ms", 0) or 0),
-                            parent_hash=obj.get("parent_hash"),
-                        )
-                    except Exception:  # noqa: BLE001  (the reference logs and skips the claim, lb/node.py:508-510)
-                        continue
-            elif t == "retract":
-                ch = tx.get("claim_hash")
-                if isinstance(ch, str):
-                    new_graph.retract(ch)
-        g.graph = new_graph
+        group = self._require_group(group_id)
+        fresh = ContextGraph()
+        for op, claim_hash, fields in _replay_ops(txs):
+            if op == "retract":
+                fresh.retract(claim_hash)
+            else:
+                fresh.add_claim(claim_hash, **fields)
+        group.graph = fresh
 
     def compile_context_many(self, group_id: str, queries: Sequence[str], *, top_k: int = 8,
                              since_ms: Optional[int] = None, lazy: bool = False) -> List[Tuple[str, List[str]]]:
