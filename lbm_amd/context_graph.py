@@ -133,7 +133,7 @@ class Claim:  # lb/context_graph.py:10-43
     tags: List[str]
     created_ms: int
     evidence: List[str]
-    parent_hash: Optional[str] = None  # For claim threading/conversations
+    parent_hash: Optional[str] = None  # the claim this one answers, if any (carried, never ranked on)
     retracted: bool = False
 
     def __setattr__(self, name: str, value: Any) -> None:
@@ -146,41 +146,36 @@ class Claim:  # lb/context_graph.py:10-43
             owner[0]._touch(owner[1])
 
     def to_dict(self) -> Dict[str, Any]:
-        d = {
-            "claim_hash": self.claim_hash,
-            "text": self.text,
-            "tags": list(self.tags),
-            "created_ms": int(self.created_ms),
-            "evidence": list(self.evidence),
-            "retracted": bool(self.retracted),
-        }
+        """The stored form (lb/context_graph.py:20-31): the fields of ``_STORED`` in that order, ``parent_hash`` only when set."""
+        out: Dict[str, Any] = {"claim_hash": self.claim_hash, "text": self.text}
+        for name, conv, _ in _STORED[2:]:
+            out[name] = conv(getattr(self, name))
         if self.parent_hash is not None:
-            d["parent_hash"] = self.parent_hash
-        return d
+            out["parent_hash"] = self.parent_hash
+        return out
 
     @staticmethod
     def from_dict(d: Dict[str, Any]) -> "Claim":
-        return Claim(
-            claim_hash=str(d["claim_hash"]),
-            text=str(d.get("text", "")),
-            tags=list(d.get("tags", [])),
-            created_ms=int(d.get("created_ms", 0)),
-            evidence=list(d.get("evidence", [])),
-            parent_hash=d.get("parent_hash"),
-            retracted=bool(d.get("retracted", False)),
-        )
+        """lb/context_graph.py:33-43: ``claim_hash`` is required, every other field falls back to its default."""
+        rest = {name: conv(d.get(name, default)) for name, conv, default in _STORED[1:]}
+        return Claim(claim_hash=str(d["claim_hash"]), parent_hash=d.get("parent_hash"), **rest)
+
+
+# stored fields of a claim: (name, coercion applied when reading / writing the stored form, default when a stored dict lacks it)
+_STORED = (("claim_hash", str, None), ("text", str, ""), ("tags", list, ()), ("created_ms", int, 0), ("evidence", list, ()),
+           ("retracted", bool, False))
 
 
 def format_context(query: str, chosen: Sequence[Tuple[str, Sequence[str]]]) -> str:
-    """lb/context_graph.py:122-133 on (text, tags) pairs."""
-    lines = ["Context slice", f"Query: {query}", ""]
-    for i, (text, tags) in enumerate(chosen, 1):
-        tag_str = (", ".join(tags)) if tags else ""
-        if tag_str:
-            lines.append(f"{i}. {text}  [tags: {tag_str}]")
-        else:
-            lines.append(f"{i}. {text}")
-    return "\n".join(lines).strip() + "\n"
+    """The context text of lb/context_graph.py:122-133 from (text, tags) pairs: a two-line header, a blank line, one
+    numbered line per claim (tags appended when their joined form is non-empty), surrounding whitespace stripped, one
+    final newline."""
+    def entry(i: int, text: str, tags: Sequence[str]) -> str:
+        label = ", ".join(tags) if tags else ""
+        return f"{i}. {text}  [tags: {label}]" if label else f"{i}. {text}"
+
+    body = "\n".join(entry(i, text, tags) for i, (text, tags) in enumerate(chosen, 1))
+    return f"Context slice\nQuery: {query}\n\n{body}".strip() + "\n"
 
 
 class LazyContext:
@@ -377,7 +372,8 @@ class _EmbeddingCacheView:
 
 
 class ContextGraph:
-    """Truth-maintenance flavored graph (v1) -- GPU-ranked drop-in (lb/context_graph.py:46-148)."""
+    """Drop-in for the reference's claim graph (lb/context_graph.py:46-148): the ``claims`` dict stays on the host, the
+    vectors and everything ``compile`` ranks on live in HBM, mirrored incrementally."""
 
     # compile() releases the graph lock while its search runs on the device (the index's own reader/writer lock and
     # per-search slots take over), so queries from several threads overlap like the reference's lock-free
@@ -694,7 +690,7 @@ class ContextGraph:
         self, query: str, *, top_k: int = 8, since_ms: Optional[int] = None, tags: Optional[Sequence[str]] = None,
         lazy: bool = False,
     ) -> Tuple[str, List[str]]:
-        """Compile context slice from claims (lb/context_graph.py:91-133).
+        """The reference's ``compile`` (lb/context_graph.py:91-133): rank the live claims against ``query``, format the best.
 
         Extensions, both off by default: ``tags`` keeps only claims carrying at least one of these tags;
         ``lazy=True`` returns a ``LazyContext`` (hashes now, text formatted on first use).
