@@ -423,8 +423,8 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
     __shared__ int nsurv, gbase;
     __shared__ uint32_t sh_bthr;
     if (wave == 0) {
-        const uint32_t c = shared_cut(bthr);
-        if (lane == 0) { nsurv = 0; sh_bthr = c; }
+        const uint32_t cut = shared_cut(bthr);
+        if (lane == 0) { nsurv = 0; sh_bthr = cut; }
     }
     __syncthreads();
     bthr = sh_bthr;  // one value for the whole block
