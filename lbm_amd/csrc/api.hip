@@ -49,7 +49,7 @@ struct lbh_ctx {
     int n_cu = 256;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;            // H2D copies of lbh_index_add's text slices (overlap with K1 on `stream`)
-    hipEvent_t copy_ev[LBH_ADD_SLICES] = {};
+    hipEvent_t copy_ev[LBH_ADD_SLICES + 1] = {};  // one per slice of text + one for the metadata columns
     std::string arch;
     int scan_blocks_per_cu = 0;  // tuning knobs (env LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT); 0 = by index size (lbh_scan_grid)
     int scan_nt = 1;
@@ -127,7 +127,7 @@ int ensure_ctx_scratch(lbh_ctx* c, int64_t text_bytes, int64_t n_off, int64_t n_
     if (text_bytes > c->d_text_cap) {
         if (c->d_text) (void)hipFree(c->d_text);
         c->d_text = nullptr;
-        int64_t cap = std::max<int64_t>(text_bytes, 1 << 16);
+        int64_t cap = std::max<int64_t>(text_bytes + text_bytes / 8, 1 << 16);  // headroom: the next batch of about this size must not re-allocate
         HIP_TRY(hipMalloc((void**)&c->d_text, (size_t)cap));
         c->d_text_cap = cap;
     }
@@ -830,25 +830,32 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
     // Per-claim metadata goes straight from the caller's arrays to their device columns (asynchronous DMA when the
     // arrays are pinned -- lbh_host_alloc -- else the runtime stages them); the 32 key bytes are decoded into their four
     // big-endian words by a kernel, not by a host loop.
-    HIP_TRY(hipMemcpyAsync(ix->created + r0, created_ms, (size_t)n * 8, hipMemcpyHostToDevice, s));
-    if (tagmask) HIP_TRY(hipMemcpyAsync(ix->tags + r0, tagmask, (size_t)n * 8, hipMemcpyHostToDevice, s));
-    else HIP_TRY(hipMemsetAsync(ix->tags + r0, 0, (size_t)n * 8, s));
-    HIP_TRY(hipMemcpyAsync(ix->keys + r0 * 4, hashkey, (size_t)n * 32, hipMemcpyHostToDevice, s));
-    HIP_TRY(lbh_launch_bswap_u64(ix->keys + r0 * 4, n * 4, s));
-    HIP_TRY(lbh_launch_iota_u64(ix->order + r0, (uint64_t)ix->row_of_id.size(), n, s));
-    HIP_TRY(lbh_launch_iota_u64(ix->ids + r0, (uint64_t)ix->row_of_id.size(), n, s));
+    auto copy_metadata = [&](hipStream_t cs) -> int {
+        HIP_TRY(hipMemcpyAsync(ix->created + r0, created_ms, (size_t)n * 8, hipMemcpyHostToDevice, cs));
+        if (tagmask) HIP_TRY(hipMemcpyAsync(ix->tags + r0, tagmask, (size_t)n * 8, hipMemcpyHostToDevice, cs));
+        else HIP_TRY(hipMemsetAsync(ix->tags + r0, 0, (size_t)n * 8, cs));
+        HIP_TRY(hipMemcpyAsync(ix->keys + r0 * 4, hashkey, (size_t)n * 32, hipMemcpyHostToDevice, cs));
+        return LBH_OK;
+    };
+    auto finish_metadata = [&]() -> int {
+        HIP_TRY(lbh_launch_bswap_u64(ix->keys + r0 * 4, n * 4, s));
+        HIP_TRY(lbh_launch_iota_u64(ix->order + r0, (uint64_t)ix->row_of_id.size(), n, s));
+        HIP_TRY(lbh_launch_iota_u64(ix->ids + r0, (uint64_t)ix->row_of_id.size(), n, s));
+        return LBH_OK;
+    };
     double batch_norm = 1.0;  // K1 writes unit vectors (or zero)
     std::vector<int64_t> rel;  // must outlive the copies below: freed after the final synchronise
     std::unique_lock<std::mutex> text_lk(c->mu, std::defer_lock);  // the context's text scratch, held until the final synchronise
     if (emb_f64) {
         batch_norm = 0.0;
         for (int64_t i = 0; i < n; ++i) batch_norm = std::max(batch_norm, vec_norm(emb_f64 + i * 64));
-        if (!(batch_norm <= 1e15)) {
-            (void)hipStreamSynchronize(s);
-            return fail(LBH_E_INVALID, "a vector is not finite (or its norm exceeds 1e15)");
-        }
+        if (!(batch_norm <= 1e15)) return fail(LBH_E_INVALID, "a vector is not finite (or its norm exceeds 1e15)");
+        int rc = copy_metadata(s);
+        if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(ix->emb64 + r0 * 64, emb_f64, (size_t)n * 512, hipMemcpyHostToDevice, s));
         HIP_TRY(lbh_launch_f64_to_f32(ix->emb64 + r0 * 64, ix->emb32 + r0 * 64, n * 64, s));
+        rc = finish_metadata();
+        if (rc) return rc;
     } else {
         const int64_t base = offsets[0], bytes = offsets[n] - base;
         bool bad = bytes < 0 || (bytes > 0 && !utf8);
@@ -856,12 +863,9 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
             const int64_t l = offsets[i + 1] - offsets[i];
             bad = l < 0 || l >= (int64_t)0x7FFFFF00;
         }
-        if (bad) {
-            (void)hipStreamSynchronize(s);
-            return fail(LBH_E_INVALID, "bad offsets (a text has a negative length or 2 GiB and more)");
-        }
+        if (bad) return fail(LBH_E_INVALID, "bad offsets (a text has a negative length or 2 GiB and more)");
         text_lk.lock();
-        const int rc = ensure_ctx_scratch(c, bytes + 64, n + 1, 0);
+        int rc = ensure_ctx_scratch(c, bytes + 64, n + 1, 0);
         if (rc) return rc;
         const int64_t* offp = offsets;
         if (base != 0) {
@@ -871,6 +875,8 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
         }
         // The batch is cut into slices: slice i + 1's text and offsets cross PCIe on the copy stream while K1 vectorises
         // slice i on the compute stream (offsets stay absolute into the one text blob, so a slice is just a pointer pair).
+        // K1 needs none of the metadata columns, so those follow the LAST slice of text on the copy stream and arrive under
+        // K1 as well (ahead of the text they kept K1 waiting for 48 bytes per claim: 1.1 of 6.4 ms per million claims).
         const int n_sl = (int)std::max<int64_t>(1, std::min<int64_t>(LBH_ADD_SLICES, n / 65536));
         for (int sl = 0; sl < n_sl; ++sl) {
             const int64_t a = n * sl / n_sl, b2 = n * (sl + 1) / n_sl;
@@ -880,7 +886,15 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
             HIP_TRY(hipEventRecord(c->copy_ev[sl], c->copy_stream));
             HIP_TRY(hipStreamWaitEvent(s, c->copy_ev[sl], 0));
             HIP_TRY(lbh_launch_embed(c->d_text, c->d_off + a, b2 - a, ix->emb64 + (r0 + a) * 64, ix->emb32 + (r0 + a) * 64, s));
+            if (sl == n_sl - 1) {
+                rc = copy_metadata(c->copy_stream);
+                if (rc) return rc;
+                HIP_TRY(hipEventRecord(c->copy_ev[LBH_ADD_SLICES], c->copy_stream));
+                HIP_TRY(hipStreamWaitEvent(s, c->copy_ev[LBH_ADD_SLICES], 0));
+            }
         }
+        rc = finish_metadata();
+        if (rc) return rc;
     }
     const uint64_t id0 = (uint64_t)ix->row_of_id.size();
     ix->row_of_id.resize(ix->row_of_id.size() + (size_t)n);

@@ -21,7 +21,7 @@ for _ in range(5):
     ix.search_shard(q, 8, _hip.SINCE_NONE, 0, st)
 out = np.zeros((2048, 6), dtype=np.int64)
 lib.lbh_debug_k2_times(out.ctypes.data_as(ctypes.c_void_p))
-g = min(512, (n + 255) // 256)
+g = int(os.environ.get("K2_BLOCKS", "0")) or min(256 if n <= 2_000_000 else 512, (n + 255) // 256)
 t = out[:g].astype(np.float64) / 100.0  # us
 t0 = t[:, 0].min()
 names = ["start", "loop done", "wave compact", "barrier", "sorted+cut", "written"]
@@ -33,3 +33,20 @@ d = np.diff(t, axis=1)
 if os.environ.get("K2_DUMP"):
     np.save(os.environ["K2_DUMP"], t - t0)
 print("  per-block phase medians (us):", {names[i + 1]: round(float(np.median(d[:, i])), 2) for i in range(5)})
+# Are the late blocks the same ones every time?  Loop-end offsets of each block over repeated searches: their correlation
+# from run to run and their mean by blockIdx % 8 (the XCD a block is dispatched to).
+runs = []
+for _ in range(8):
+    ix.search_shard(q, 8, _hip.SINCE_NONE, 0, st)
+    lib.lbh_debug_k2_times(out.ctypes.data_as(ctypes.c_void_p))
+    r = out[:g].astype(np.float64) / 100.0
+    runs.append(r[:, 1] - r[:, 0].min())
+runs = np.array(runs)
+cc = np.corrcoef(runs)
+print(f"  loop-end offsets over 8 searches: run-to-run correlation median {np.median(cc[np.triu_indices(8, 1)]):.2f}")
+mean = runs.mean(axis=0)
+print("  mean loop end by blockIdx % 8 (us):", [round(float(mean[x::8].mean()), 1) for x in range(8)])
+print("  mean loop end by blockIdx // 32 (us):", [round(float(mean[x * 32:(x + 1) * 32].mean()), 1) for x in range(g // 32)])
+late = np.argsort(mean)[-16:]
+print("  16 latest blocks on average:", sorted(int(b) for b in late), "their mean", round(float(mean[late].mean()), 1),
+      "all-block mean", round(float(mean.mean()), 1), "max of per-run last", round(float(runs.max(axis=1).mean()), 1))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B the scan kernel's launch knobs in ONE process (interleaved rounds, median + min).
 Usage: python tools/tune_scan.py [claims] [top_k] [scan_mode]"""
-import sys, os, time
+import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lbm_amd import _hip
