@@ -18,6 +18,9 @@
 
 #include "lbh_internal.h"
 
+// No exception may cross the C ABI: entry points that grow host containers are function-try-blocks ending in this.
+#define LBH_CATCH_ALLOC catch (const std::bad_alloc&) { return fail(LBH_E_NOMEM, "out of host memory"); }
+
 namespace {
 
 thread_local std::string g_err;
@@ -42,7 +45,7 @@ int fail(int code, const char* fmt, ...) {
 
 }  // namespace
 
-#define LBH_ADD_SLICES 8  // most slices one lbh_index_add call is cut into
+#define LBH_ADD_SLICES 4  // most slices one lbh_index_add call is cut into
 
 struct lbh_ctx {
     int device = 0;
@@ -176,6 +179,12 @@ int index_reserve_locked(lbh_index* ix, int64_t want) {
         (void)hipFree(ix->emb16);
         ix->emb16 = nullptr;
         ix->emb16_rows = ix->emb16_cap = 0;
+    }
+    try {  // the host-side id maps grow with the device columns, so that no ingest call pays a vector re-allocation
+        ix->id_of_row.reserve((size_t)want);
+        ix->row_of_id.reserve(ix->row_of_id.size() + (size_t)(want - ix->n));
+    } catch (const std::bad_alloc&) {
+        return fail(LBH_E_NOMEM, "out of host memory");
     }
     ix->cap = want;
     return LBH_OK;
@@ -711,7 +720,7 @@ int lbh_embed_batch(lbh_ctx* c, const uint8_t* utf8, const int64_t* offsets, int
     return lbh_embed_batch_dim(c, utf8, offsets, n, LBH_DIM, out_f64);
 }
 
-int lbh_embed_batch_dim(lbh_ctx* c, const uint8_t* utf8, const int64_t* offsets, int64_t n, int dim, double* out_f64) {
+int lbh_embed_batch_dim(lbh_ctx* c, const uint8_t* utf8, const int64_t* offsets, int64_t n, int dim, double* out_f64) try {
     if (!c || n < 0 || (n > 0 && (!offsets || !out_f64))) return fail(LBH_E_INVALID, "bad argument");
     if (dim < 1 || dim > LBH_DIM) return fail(LBH_E_INVALID, "dim must be in 1..64 (a token only has 64 digest bytes, lb/latent.py:49-52)");
     if (n == 0) return LBH_OK;
@@ -738,7 +747,7 @@ int lbh_embed_batch_dim(lbh_ctx* c, const uint8_t* utf8, const int64_t* offsets,
     HIP_TRY(hipMemcpyAsync(out_f64, c->d_vec, (size_t)n * 64 * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return LBH_OK;
-}
+} LBH_CATCH_ALLOC
 
 int lbh_embed_batch_dev(lbh_ctx* c, const uint8_t* utf8_dev, const int64_t* offsets_dev, int64_t n, int64_t total_bytes,
                         double* out_f64_dev, float* out_f32_dev) {
@@ -812,7 +821,7 @@ int lbh_index_reserve(lbh_index* ix, int64_t capacity) {
 }
 
 int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t* utf8, const int64_t* offsets,
-                  const int64_t* created_ms, const uint64_t* tagmask, const uint8_t* hashkey, uint64_t* out_ids) {
+                  const int64_t* created_ms, const uint64_t* tagmask, const uint8_t* hashkey, uint64_t* out_ids) try {
     if (!ix || n < 0) return fail(LBH_E_INVALID, "bad argument");
     if (n == 0) return LBH_OK;
     if ((emb_f64 != nullptr) == (offsets != nullptr)) return fail(LBH_E_INVALID, "pass either emb_f64 or (utf8, offsets)");
@@ -826,6 +835,9 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
         int rc = index_reserve_locked(ix, want);
         if (rc) return rc;
     }
+    // host id maps first: nothing below may fail for want of host memory once GPU work has been queued
+    ix->row_of_id.reserve(ix->row_of_id.size() + (size_t)n);
+    ix->id_of_row.reserve((size_t)(ix->n + n));
     const int64_t r0 = ix->n;
     // Per-claim metadata goes straight from the caller's arrays to their device columns (asynchronous DMA when the
     // arrays are pinned -- lbh_host_alloc -- else the runtime stages them); the 32 key bytes are decoded into their four
@@ -877,9 +889,14 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
         // slice i on the compute stream (offsets stay absolute into the one text blob, so a slice is just a pointer pair).
         // K1 needs none of the metadata columns, so those follow the LAST slice of text on the copy stream and arrive under
         // K1 as well (ahead of the text they kept K1 waiting for 48 bytes per claim: 1.1 of 6.4 ms per million claims).
+        // Slices grow geometrically: a short first one lets K1 start after 1/16 of the text has crossed, and every later
+        // slice's copy ends before the K1 launch ahead of it does (PCIe moves a claim's ~170 bytes in half of K1's time per
+        // claim) -- few, large launches, because each K1 launch pays its own ramp and tail (8 equal slices of a 1 M-claim
+        // batch took 8 x 0.61 ms against 4.1 ms in one launch).
+        static const int cut16[LBH_ADD_SLICES][LBH_ADD_SLICES + 1] = {{0, 16}, {0, 4, 16}, {0, 2, 6, 16}, {0, 1, 3, 7, 16}};
         const int n_sl = (int)std::max<int64_t>(1, std::min<int64_t>(LBH_ADD_SLICES, n / 65536));
         for (int sl = 0; sl < n_sl; ++sl) {
-            const int64_t a = n * sl / n_sl, b2 = n * (sl + 1) / n_sl;
+            const int64_t a = n * cut16[n_sl - 1][sl] / 16, b2 = n * cut16[n_sl - 1][sl + 1] / 16;
             const int64_t t0 = offp[a], t1 = offp[b2];
             if (t1 > t0) HIP_TRY(hipMemcpyAsync(c->d_text + t0, utf8 + base + t0, (size_t)(t1 - t0), hipMemcpyHostToDevice, c->copy_stream));
             HIP_TRY(hipMemcpyAsync(c->d_off + a, offp + a, (size_t)(b2 - a + 1) * 8, hipMemcpyHostToDevice, c->copy_stream));
@@ -916,7 +933,7 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
         return fail(LBH_E_DEVICE, "lbh_index_add: %s", hipGetErrorString(e_sync));
     }
     return LBH_OK;
-}
+} LBH_CATCH_ALLOC
 
 int lbh_index_retract(lbh_index* ix, uint64_t id) {
     if (!ix) return fail(LBH_E_INVALID, "bad argument");
@@ -938,7 +955,7 @@ int lbh_index_retract(lbh_index* ix, uint64_t id) {
     return LBH_OK;
 }
 
-int lbh_index_retract_many(lbh_index* ix, int64_t n, const uint64_t* ids) {
+int lbh_index_retract_many(lbh_index* ix, int64_t n, const uint64_t* ids) try {
     if (!ix || n < 0 || (n > 0 && !ids)) return fail(LBH_E_INVALID, "bad argument");
     if (n == 0) return LBH_OK;
     Exclusive lk(ix);
@@ -995,7 +1012,7 @@ int lbh_index_retract_many(lbh_index* ix, int64_t n, const uint64_t* ids) {
     else ix->emb16_rows = std::min(ix->emb16_rows, n_new);  // only reached without moves: the converted prefix stays valid
     ix->n = n_new;
     return LBH_OK;
-}
+} LBH_CATCH_ALLOC
 
 int lbh_index_get_embeddings(lbh_index* ix, int64_t n, const uint64_t* ids, double* out_f64) {
     if (!ix || n < 0 || (n > 0 && (!ids || !out_f64))) return fail(LBH_E_INVALID, "bad argument");
@@ -1039,7 +1056,7 @@ int lbh_index_update_meta(lbh_index* ix, uint64_t id, int64_t created_ms, uint64
     return LBH_OK;
 }
 
-int lbh_index_set_keys(lbh_index* ix, int64_t n, const uint64_t* ids, const uint8_t* hashkey) {
+int lbh_index_set_keys(lbh_index* ix, int64_t n, const uint64_t* ids, const uint8_t* hashkey) try {
     if (!ix || n < 0 || (n > 0 && (!ids || !hashkey))) return fail(LBH_E_INVALID, "bad argument");
     if (n == 0) return LBH_OK;
     Exclusive lk(ix);
@@ -1058,7 +1075,7 @@ int lbh_index_set_keys(lbh_index* ix, int64_t n, const uint64_t* ids, const uint
     HIP_TRY(hipMemcpyAsync(ix->keys, host.data(), host.size() * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
     return LBH_OK;
-}
+} LBH_CATCH_ALLOC
 
 int lbh_index_set_order(lbh_index* ix, int64_t n, const uint64_t* ids, const uint64_t* order) {
     if (!ix || n < 0 || (n > 0 && (!ids || !order))) return fail(LBH_E_INVALID, "bad argument");
@@ -1149,7 +1166,7 @@ int lbh_index_recent(lbh_index* ix, int64_t since_ms, int64_t limit, uint64_t* o
     });
 }
 
-int lbh_merge_topk(const int64_t* lists, int64_t n_lists, int64_t k, int64_t* out_entries, int64_t* out_count) {
+int lbh_merge_topk(const int64_t* lists, int64_t n_lists, int64_t k, int64_t* out_entries, int64_t* out_count) try {
     if (n_lists < 0 || k < 0 || (n_lists > 0 && !lists) || !out_count || (k > 0 && !out_entries))
         return fail(LBH_E_INVALID, "bad argument");
     struct Ref { double s; const int64_t* e; };
@@ -1179,7 +1196,7 @@ int lbh_merge_topk(const int64_t* lists, int64_t n_lists, int64_t k, int64_t* ou
     for (size_t i = 0; i < take; ++i) memcpy(out_entries + i * 6, all[i].e, 48);
     *out_count = (int64_t)take;
     return LBH_OK;
-}
+} LBH_CATCH_ALLOC
 
 int lbh_index_size(lbh_index* ix, int64_t* out_live) {
     if (!ix || !out_live) return fail(LBH_E_INVALID, "bad argument");
@@ -1200,7 +1217,7 @@ int lbh_index_get_embedding(lbh_index* ix, uint64_t id, double* out64) {
 }
 
 int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, int64_t since_ms, uint64_t tag_mask,
-                     uint64_t* out_ids, double* out_scores, int64_t* out_counts, lbh_stats* stats) {
+                     uint64_t* out_ids, double* out_scores, int64_t* out_counts, lbh_stats* stats) try {
     if (!ix || nq < 0 || (nq > 0 && (!q_f64 || !out_counts))) return fail(LBH_E_INVALID, "bad argument");
     if (k < 0) k = 0;
     if (k > 0 && nq > 0 && (!out_ids || !out_scores)) return fail(LBH_E_INVALID, "output arrays are NULL");
@@ -1305,7 +1322,7 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
     }
     return LBH_OK;
     });
-}
+} LBH_CATCH_ALLOC
 
 int lbh_index_search_text(lbh_index* ix, const uint8_t* utf8, int64_t len, int64_t k, int64_t since_ms, uint64_t tag_mask,
                           uint64_t* out_ids, double* out_scores, int64_t* out_count, double* out_qvec64, lbh_stats* stats) {
@@ -1513,7 +1530,7 @@ int lbh_comm_init(lbh_ctx* c, const uint8_t* id, int rank, int world, lbh_comm**
 
 int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, int64_t k, int64_t since_ms, uint64_t tag_mask,
                              uint64_t gid_mul, uint64_t gid_add, uint64_t* out_gids, double* out_scores, uint8_t* out_keys,
-                             int64_t* out_count, lbh_stats* stats) {
+                             int64_t* out_count, lbh_stats* stats) try {
     if (!ix || !cm || !q_f64 || !out_count) return fail(LBH_E_INVALID, "bad argument");
     if (cm->ctx != ix->ctx) return fail(LBH_E_INVALID, "the communicator and the index belong to different contexts");
     if (k < 0) k = 0;
@@ -1647,6 +1664,6 @@ int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, i
     *out_count = cnt;
     return LBH_OK;
     });
-}
+} LBH_CATCH_ALLOC
 
 }  // extern "C"

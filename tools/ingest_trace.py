@@ -18,3 +18,19 @@ for ci in range(4):
     for p in pins:
         p.close()
 ix.close()
+
+# the bench's own loop shape: ordinary numpy arrays, 1 % of each chunk retracted right after
+import numpy as np
+ix = _hip.Index()
+ix.reserve(4 * chunk)
+for ci in range(4):
+    ch = synth.make_chunk(ci * chunk, chunk, seed=1234, chunk_index=ci, real_sha_keys=False)
+    t0 = time.perf_counter()
+    ids = ix.add_texts(ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)
+    t1 = time.perf_counter()
+    dead = ids[ch.retracted]
+    t2 = time.perf_counter()
+    ix.retract_many(dead)
+    t3 = time.perf_counter()
+    print(f"pageable call {ci}: add {1e3 * (t1 - t0):.2f} ms, pick ids {1e3 * (t2 - t1):.2f} ms, retract_many({len(dead)}) {1e3 * (t3 - t2):.2f} ms", flush=True)
+ix.close()
