@@ -360,6 +360,9 @@ int ensure_emb16(lbh_index* ix);
 // run a search body under a lease; when it reports the fp16 copy out of date, bring it up to date exclusively and retry
 template <class Body>
 int with_lease(lbh_index* ix, Body&& body) {
+    // the calling thread's current device is its own business (a fresh thread starts on device 0): everything below --
+    // a slot created on first overlap included -- belongs on the index's device
+    HIP_TRY(hipSetDevice(ix->ctx->device));
     for (int attempt = 0;; ++attempt) {
         int rc;
         {
