@@ -182,7 +182,8 @@ int index_reserve_locked(lbh_index* ix, int64_t want) {
     }
     try {  // the host-side id maps grow with the device columns, so that no ingest call pays a vector re-allocation
         ix->id_of_row.reserve((size_t)want);
-        ix->row_of_id.reserve(ix->row_of_id.size() + (size_t)(want - ix->n));
+        if (ix->row_of_id.capacity() < ix->row_of_id.size() + (size_t)(want - ix->n))
+            ix->row_of_id.reserve(std::max(ix->row_of_id.size() + (size_t)(want - ix->n), 2 * ix->row_of_id.capacity()));
     } catch (const std::bad_alloc&) {
         return fail(LBH_E_NOMEM, "out of host memory");
     }
@@ -839,8 +840,11 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
         if (rc) return rc;
     }
     // host id maps first: nothing below may fail for want of host memory once GPU work has been queued
-    ix->row_of_id.reserve(ix->row_of_id.size() + (size_t)n);
-    ix->id_of_row.reserve((size_t)(ix->n + n));
+    // (geometric: reserve() to the exact size would re-allocate and copy the ever-growing id map on every call)
+    if (ix->row_of_id.capacity() < ix->row_of_id.size() + (size_t)n)
+        ix->row_of_id.reserve(std::max(ix->row_of_id.size() + (size_t)n, 2 * ix->row_of_id.capacity()));
+    if (ix->id_of_row.capacity() < (size_t)(ix->n + n))
+        ix->id_of_row.reserve(std::max((size_t)(ix->n + n), 2 * ix->id_of_row.capacity()));
     const int64_t r0 = ix->n;
     // Per-claim metadata goes straight from the caller's arrays to their device columns (asynchronous DMA when the
     // arrays are pinned -- lbh_host_alloc -- else the runtime stages them); the 32 key bytes are decoded into their four

@@ -45,22 +45,28 @@ def ingest_prepacked(n_chunks=4, chunk=1_000_000):
     ix = _hip.Index()
     ix.reserve(n_chunks * chunk)
     t_pin = t_page = 0.0
+    pin_calls, page_calls = [], []
     for ci in range(n_chunks):
         ch = synth.make_chunk(ci * chunk, chunk, seed=1234, chunk_index=ci, real_sha_keys=False)
         pins = [_hip.pinned_like(a) for a in (ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)]
         t0 = time.perf_counter()
         ids = ix.add_texts(*(p.a for p in pins))
-        t_pin += time.perf_counter() - t0
+        pin_calls.append(time.perf_counter() - t0)
+        t_pin += pin_calls[-1]
         ix.retract_many(ids)  # same rows again from ordinary (pageable) numpy arrays
         t0 = time.perf_counter()
         ix.add_texts(ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)
-        t_page += time.perf_counter() - t0
+        page_calls.append(time.perf_counter() - t0)
+        t_page += page_calls[-1]
         for p in pins:
             p.close()
     ix.close()
     return {"claims": n_chunks * chunk, "pinned_buffers_claims_per_s": n_chunks * chunk / t_pin,
             "pageable_buffers_claims_per_s": n_chunks * chunk / t_page,
-            "note": "1 M-claim calls, ~112 B of text + 56 B of metadata per claim; K1 alone runs at ~243 M claims/s"}
+            "pinned_call_ms": [round(1e3 * t, 3) for t in pin_calls], "pageable_call_ms": [round(1e3 * t, 3) for t in page_calls],
+            "pinned_buffers_claims_per_s_median_call": chunk / float(np.median(pin_calls)),
+            "pageable_buffers_claims_per_s_median_call": chunk / float(np.median(page_calls)),
+            "note": "1 M-claim calls, ~112 B of text + 56 B of metadata per claim; K1 alone runs at ~243 M claims/s; every chunk is added, retracted whole and added again, so the id map doubles now and then (the slow call)"}
 
 
 def time_single(ix, qv, k, since, tmask, reps=60):
