@@ -53,8 +53,9 @@ def _worker(rank, world, port, n, out_q):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_allgather_merge_equals_single_corpus():
-    world, n = 2, 3000
+@pytest.mark.parametrize("world", [2, 5])
+def test_allgather_merge_equals_single_corpus(world):
+    n = 3000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -173,11 +174,12 @@ def _graph_worker(rank, world, port, out_q):
     out_q.put((rank, ok))
 
 
-@pytest.mark.timeout(300)
-def test_sharded_context_graph_two_ranks_equals_reference_golden():
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("world", [2, 5])
+def test_sharded_context_graph_equals_reference_golden(world):
     """Graph-level sharding (north_star: compile_context over a claim-sharded corpus returns hash-identical top-k):
-    two gloo ranks, each holding the claims it owns in an oracle-backed index, answer the reference's golden queries."""
-    world = 2
+    gloo ranks (two; five: uneven ownership, and shards of the ten-claim graph that are empty), each holding the claims it
+    owns in an oracle-backed index, answer the reference's golden queries."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
