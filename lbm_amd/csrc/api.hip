@@ -491,7 +491,7 @@ int run_page(lbh_index* ix, lbh_slot* sl, int page, int64_t since_ms, uint64_t t
         if (half && !emb16_current(ix)) return LBH_NEED_EMB16;
         if (fast)
             HIP_TRY(lbh_launch_search_fast(dv, half ? ix->emb16 : nullptr, sl->ws, sl->qptr, sl->qarg, page, has_since, since_ms,
-                                           tag_mask, grid, c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, e0, e1));
+                                           tag_mask, half ? lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu, true) : grid, c->n_cu, c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, e0, e1));
         else {
             const int xgrid = std::min(grid, 512);
             HIP_TRY(lbh_launch_search_exact(dv, sl->ws, sl->qptr, sl->qarg, page, has_since, since_ms, tag_mask, cur, xgrid, seq, s, e0, e1));
@@ -655,6 +655,12 @@ int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx) {
     if (const char* e1 = getenv("LBH_SCAN_BLOCKS_PER_CU")) c->scan_blocks_per_cu = std::max(0, std::min(8, atoi(e1)));
     if (const char* e2 = getenv("LBH_SCAN_NT")) c->scan_nt = atoi(e2) != 0;
     if (const char* e5 = getenv("LBH_SCAN_MODE")) c->scan_mode = atoi(e5) != 0;
+    if (const char* e6 = getenv("LBH_SCAN_SPLIT")) {  // "a,b,c,d": tile shares of the scan's four block classes (lbh_split); "0" = grid-stride
+        unsigned w[4] = {0, 0, 0, 0};
+        const int got = sscanf(e6, "%u,%u,%u,%u", &w[0], &w[1], &w[2], &w[3]);
+        const uint32_t ww[4] = {std::min(w[0], 65535u), std::min(w[1], 65535u), std::min(w[2], 65535u), std::min(w[3], 65535u)};
+        if (got == 4 || got == 1) lbh_set_scan_split(ww);
+    }
     if (const char* e4 = getenv("LBH_BQ_MODE")) c->bq_mode = std::max(0, std::min(2, atoi(e4)));
     if (const char* e3 = getenv("LBH_SPIN_US")) c->spin_us = std::max(0, std::min(1000000, atoi(e3)));
     hipError_t e0 = hipSetDevice(c->device);
@@ -1578,8 +1584,9 @@ int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, i
             const int grid = lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu);
             const bool half = c->scan_mode == 1 && nscale <= 1.001f && nscale >= 0.25f;
             if (half && !emb16_current(ix)) return LBH_NEED_EMB16;
-            HIP_TRY(lbh_launch_search_fast(dv, half ? ix->emb16 : nullptr, sl->ws, nullptr, sl->qarg, page, has_since, since_ms, tag_mask, grid,
-                                           c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, timing ? sl->ev[0] : nullptr,
+            HIP_TRY(lbh_launch_search_fast(dv, half ? ix->emb16 : nullptr, sl->ws, nullptr, sl->qarg, page, has_since, since_ms, tag_mask,
+                                           half ? lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu, true) : grid,
+                                           c->n_cu, c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, timing ? sl->ev[0] : nullptr,
                                            timing ? sl->ev[1] : nullptr, &xc));
             lbh_cursor cur;
             memset(&cur, 0, sizeof cur);

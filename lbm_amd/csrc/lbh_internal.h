@@ -90,6 +90,18 @@ struct lbh_qarg {
     double q[64];
 };
 
+// How the single-query scan divides the 64-row tiles among its blocks: block b streams the contiguous range
+// [start(b), start(b + 1)), start(b) = n_tiles x (weight of blocks below b) / (weight of all blocks).  Four weight classes:
+// even / odd blockIdx (the XCD a block lands on alternates with its index, and the odd XCDs are served ~5-10 % slower),
+// and first / later residency (block b >= n_first shares its CU with an older block whose waves win arbitration).
+// All-zero weights = the plain grid-stride loop (every block the same number of tiles).
+struct lbh_split {
+    uint32_t w[4];     // even-first, odd-first, even-later, odd-later
+    int32_t n_first;   // blocks resident first: min(grid, CUs)
+};
+lbh_split lbh_scan_split(int64_t n_rows, int grid, int n_cu);
+void lbh_set_scan_split(const uint32_t w[4]);  // tuning override (env LBH_SCAN_SPLIT, "a,b,c,d"; all 0 = grid-stride)
+
 // result block written by the final kernels (device) and copied to pinned host memory
 struct lbh_result {
     int32_t count;
@@ -167,11 +179,11 @@ hipError_t lbh_launch_iota_u64(uint64_t* dst, uint64_t first, int64_t n, hipStre
 hipError_t lbh_launch_bswap_u64(uint64_t* p, int64_t n, hipStream_t s);
 hipError_t lbh_launch_scatter_u64(uint64_t* dst, const int64_t* rows_dev, const uint64_t* vals_dev, int64_t n, hipStream_t s);
 // search.hip
-int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu);
+int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu, bool half = false);
 // emb16: NULL = scan the fp32 matrix; else the fp16 copy (opt-in scan_mode 1; `margin` must then be the fp16 one)
 hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, const double* qptr,
                                   const lbh_qarg& qa, int k, int has_since,
-                                  int64_t since_ms, uint64_t tag_mask, int grid, int nt, int seq, float margin,
+                                  int64_t since_ms, uint64_t tag_mask, int grid, int n_cu, int nt, int seq, float margin,
                                   hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const lbh_xchg* xc = nullptr);
 hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
                                    const lbh_qarg& qa, int k, int has_since,

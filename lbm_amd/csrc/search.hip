@@ -200,15 +200,31 @@ typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 #ifdef LBH_K2_TIMING  // instrumented build (tools/scripts/k2_phases.py): 100 MHz wall-clock stamps of every block's first wave
 __device__ long long lbh_k2_dbg[LBH_MAX_BLOCKS][6];
 #define K2_STAMP(i) do { if (threadIdx.x == 0) lbh_k2_dbg[blockIdx.x][i] = wall_clock64(); } while (0)
+__device__ long long lbh_k4_dbg[16];  // the same for the select kernel's phases (thread 0)
+#define K4_STAMP(i) do { if (threadIdx.x == 0) lbh_k4_dbg[i] = wall_clock64(); } while (0)
 #else
 #define K2_STAMP(i)
+#define K4_STAMP(i)
 #endif
+// first tile of block b under a weighted split (b = grid gives n_tiles): the weight of the blocks below b over the weight
+// of all, times the tile count.  Blocks [0, n_first) are the first on their CU, the rest arrive beside an older block.
+__host__ __device__ inline uint64_t split_cum(const lbh_split& sp, int b) {
+    const int f = b < sp.n_first ? b : sp.n_first;
+    const uint64_t ev1 = (uint64_t)((f + 1) / 2), od1 = (uint64_t)(f / 2);                                       // even / odd indices in [0, f)
+    const uint64_t ev2 = (uint64_t)((b + 1) / 2 - (f + 1) / 2), od2 = (uint64_t)(b / 2 - f / 2);                // ... in [f, b)
+    return ev1 * sp.w[0] + od1 * sp.w[1] + ev2 * sp.w[2] + od2 * sp.w[3];
+}
+__host__ __device__ inline int64_t split_start(const lbh_split& sp, int b, int grid, int64_t n_tiles) {
+    if (b >= grid) return n_tiles;
+    return (int64_t)(((uint64_t)n_tiles * split_cum(sp, b)) / split_cum(sp, grid));  // < 2^26 tiles x < 2^27 weight: fits
+}
+
 template <bool SINCE, bool TAGS, bool NT, bool HALF>
 __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_index ix, const uint16_t* __restrict__ emb16,
                                                                      const double* __restrict__ qptr, lbh_qarg qa,
                                                                      int k, float margin, int64_t since_ms, uint64_t tag_mask,
                                                                      uint64_t* __restrict__ cand,
-                                                                     int32_t* __restrict__ flags) {
+                                                                     int32_t* __restrict__ flags, lbh_split sp) {
     __shared__ uint64_t wbuf[LBH_SCAN_WAVES][LBH_WCAP];
     __shared__ uint64_t mbuf[LBH_SCAN_WAVES * LBH_WCAP];
     __shared__ int wcnt[LBH_SCAN_WAVES];
@@ -265,8 +281,15 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
         }
     };
 
-    for (int64_t tile = (int64_t)blockIdx.x * LBH_SCAN_WAVES + wave; tile < n_tiles && !dead;
-         tile += (int64_t)gridDim.x * LBH_SCAN_WAVES) {
+    // this block's tiles: a weighted contiguous range (lbh_split), or the grid-stride loop when the weights are all zero
+    int64_t tile = (int64_t)blockIdx.x * LBH_SCAN_WAVES + wave, tile_end = n_tiles, tile_step = (int64_t)gridDim.x * LBH_SCAN_WAVES;
+    if (sp.w[0]) {
+        const int64_t t0 = split_start(sp, (int)blockIdx.x, (int)gridDim.x, n_tiles);
+        tile_end = split_start(sp, (int)blockIdx.x + 1, (int)gridDim.x, n_tiles);
+        tile = t0 + wave;
+        tile_step = LBH_SCAN_WAVES;
+    }
+    for (; tile < tile_end && !dead; tile += tile_step) {
         float s;
         int64_t myrow;
         if (!HALF) {
@@ -540,12 +563,14 @@ __device__ void rerank_and_emit(uint64_t* xo, uint32_t* xr, int M, int k, const 
     }
     for (int j = M + tid; j < n2; j += SEL_THREADS) { xo[j] = 0; xr[j] = PAD_ROW; }
     __syncthreads();
+    K4_STAMP(3);  // exact scores
     if (n2 <= 128) {  // the usual case (M ~ k): one wave sorts without block barriers
         if (tid < 64) sort_exact(xo, xr, n2, tid, 64, ix.keys, WaveSync());
         __syncthreads();
     } else {
         sort_exact(xo, xr, n2, tid, SEL_THREADS, ix.keys, BlockSync());
     }
+    K4_STAMP(4);  // sorted
     const int cnt = M < k ? M : k;
     if (tid < cnt) {
         const uint32_t r = xr[tid];
@@ -664,6 +689,10 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
         __syncthreads();
         M = sh_cnt;
     }
+    K4_STAMP(2);  // candidates loaded and cut
+#ifdef LBH_K2_TIMING
+    if (tid == 0) lbh_k4_dbg[9] = M;
+#endif
     if (M > LBH_MCAP) {
         if (tid == 0) { res->count = 0; res->overflow = 1; res->candidates = M; }
         return;
@@ -700,10 +729,15 @@ __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index 
                                                                    lbh_result* __restrict__ res, int seq, float margin, lbh_xchg xc) {
     __shared__ double qs[64];
     const int tid = threadIdx.x;
+    K4_STAMP(0);
     const int overflowed = flags[0];
     const int E = flags[1];
     if (tid < 64) qs[tid] = qptr ? qptr[tid] : qa.q[tid];
     __syncthreads();
+    K4_STAMP(1);  // counters read
+#ifdef LBH_K2_TIMING
+    if (tid == 0) lbh_k4_dbg[8] = E;
+#endif
     if (tid < 4) flags[tid] = 0;  // leave the counters zeroed for the next launch (no memset node needed)
     if (tid >= 64 && tid < 128) flags[tid] = 0;  // and the scan blocks' shared cuts
     if (overflowed) {
@@ -711,7 +745,9 @@ __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index 
     } else {
         select_fast_body(ix, qs, k, cand, E, res, margin, xc);
     }
+    K4_STAMP(6);  // result rows written
     publish_result(res, seq);
+    K4_STAMP(7);  // fenced to the host, ticket stored
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2138,12 +2174,14 @@ hipError_t lbh_launch_recent(const int64_t* created, const uint64_t* order, int6
     return hipGetLastError();
 }
 
-int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu) {
+int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu, bool half) {
     // blocks_per_cu <= 0: by size.  Up to ~2 M rows ONE 4-wave block per CU is faster (1 M rows: scan 56 -> 50 us, 300 k:
     // 24.8 -> 23.2, 100 k: 16.2 -> 14.4): half as many block epilogues and candidate lists, and the streaming loop has too
     // few tiles per wave for a second block to hide anything.  From ~3 M rows on two blocks per CU win by 1-3 %
     // (tools/scripts/scan_block_sweep.sh; 512-thread blocks were measured too: within noise of these two).
-    if (blocks_per_cu <= 0) blocks_per_cu = n_rows <= 2000000 ? 1 : 2;
+    // The fp16 flavour (half as many bytes per tile) is faster with one block per CU at every size measured (10 M rows:
+    // 189.4 against 195.2 us, 1 M: 32.7 against 39.3; tools/scripts/scan_split_ab_fp16.sh).
+    if (blocks_per_cu <= 0) blocks_per_cu = (half || n_rows <= 2000000) ? 1 : 2;
     const int64_t tiles = (n_rows + 63) / 64;
     int64_t blocks = (tiles + LBH_SCAN_WAVES - 1) / LBH_SCAN_WAVES;
     const int64_t cap = (int64_t)n_cu * blocks_per_cu < LBH_MAX_BLOCKS ? (int64_t)n_cu * blocks_per_cu : LBH_MAX_BLOCKS;
@@ -2152,14 +2190,45 @@ int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu) {
     return (int)blocks;
 }
 
+namespace {
+uint32_t g_split_w[4] = {0, 0, 0, 0};
+bool g_split_set = false;
+}  // namespace
+
+void lbh_set_scan_split(const uint32_t w[4]) {
+    for (int i = 0; i < 4; ++i) g_split_w[i] = w[i];
+    g_split_set = true;
+}
+
+lbh_split lbh_scan_split(int64_t n_rows, int grid, int n_cu) {
+    lbh_split sp;
+    sp.n_first = grid < n_cu ? grid : n_cu;
+    // Defaults (tools/scripts/scan_split_ab.sh, same-box A/B against the grid-stride loop).  One block per CU: equal
+    // contiguous ranges -- the loop-end spread of the 1 M-claim scan narrows (last block 44 -> 40 us) and the scan goes
+    // from 50.3-51.0 to 47.8-48.1 us; shares by XCD parity change nothing on top.  Two blocks per CU: shares proportional
+    // to the rate at which each class streamed under equal shares (the second block on a CU is ~15 % slower than the
+    // first, odd XCDs ~10 % slower than even ones): 10 M claims 376-386 -> 374-376 us.  The end time barely moves with
+    // the shares -- every variant, perfectly levelled ones included, ends at 368-373 us, i.e. at ~6.9 TB/s: that is the
+    // rate this memory system sustains, not a balance problem.
+    static const uint32_t one[4] = {1000, 1000, 1000, 1000}, two[4] = {1127, 1016, 977, 880};
+    const uint32_t* w = g_split_set ? g_split_w : (grid > n_cu ? two : one);
+    for (int i = 0; i < 4; ++i) sp.w[i] = w[i];
+    const int64_t tiles = (n_rows + 63) / 64;
+    if (sp.w[0] == 0 || sp.w[1] == 0 || sp.w[2] == 0 || sp.w[3] == 0 || tiles < 2 * (int64_t)grid * LBH_SCAN_WAVES)
+        sp.w[0] = sp.w[1] = sp.w[2] = sp.w[3] = 0;  // off, or fewer than two tiles per wave: the grid-stride loop
+    return sp;
+}
+
 hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, const double* qptr,
                                   const lbh_qarg& qa, int k, int has_since,
-                                  int64_t since_ms, uint64_t tag_mask, int grid, int nt, int seq, float margin,
+                                  int64_t since_ms, uint64_t tag_mask, int grid, int n_cu, int nt, int seq, float margin,
                                   hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const lbh_xchg* xc) {
     hipError_t e;
+    // the fp16 flavour keeps the grid-stride loop: contiguous ranges cost it 2-3 % (10 M rows: 195 -> 198-201 us)
+    const lbh_split sp = emb16 ? lbh_split{{0, 0, 0, 0}, 0} : lbh_scan_split(ix.n, grid, n_cu);
     if (ev0) (void)hipEventRecord(ev0, s);
     const dim3 g(grid), b(LBH_SCAN_THREADS);
-#define LBH_SCAN_ARGS ix, emb16, qptr, qa, k, margin, since_ms, tag_mask, ws.cand, ws.flags
+#define LBH_SCAN_ARGS ix, emb16, qptr, qa, k, margin, since_ms, tag_mask, ws.cand, ws.flags, sp
 #define LBH_SCAN_DISPATCH(NTV, HV)                                                                           \
     do {                                                                                                     \
         if (has_since && tag_mask) scan_f32_kernel<true, true, NTV, HV><<<g, b, 0, s>>>(LBH_SCAN_ARGS);      \
@@ -2276,7 +2345,8 @@ hipError_t lbh_launch_search_noalloc(void* scratch_ptr, const lbh_dev_index& ix,
     int grid = lbh_scan_grid(ix.n, n_cu, 0);
     if (grid > NA_FAST_BLOCKS) grid = NA_FAST_BLOCKS;
     const dim3 g(grid), b(LBH_SCAN_THREADS);
-#define LBH_NA_ARGS ix, nullptr, nullptr, qa, k, margin, since_ms, tag_mask, cand, flags
+    const lbh_split sp = lbh_scan_split(ix.n, grid, n_cu);
+#define LBH_NA_ARGS ix, nullptr, nullptr, qa, k, margin, since_ms, tag_mask, cand, flags, sp
     if (nt) {
         if (has_since && tag_mask) scan_f32_kernel<true, true, true, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
         else if (has_since) scan_f32_kernel<true, false, true, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
@@ -2439,6 +2509,9 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* em
 #ifdef LBH_K2_TIMING
 extern "C" int lbh_debug_k2_times(long long* out) {  // instrumented build only: LBH_MAX_BLOCKS x 6 stamps
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lbh_k2_dbg), sizeof(long long) * LBH_MAX_BLOCKS * 6);
+}
+extern "C" int lbh_debug_k4_times(long long* out) {  // 16 stamps of the select kernel
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lbh_k4_dbg), sizeof(long long) * 16);
 }
 #endif
 #if LBH_BQ_ABLATE == 10

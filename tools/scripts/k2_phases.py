@@ -50,3 +50,19 @@ print("  mean loop end by blockIdx // 32 (us):", [round(float(mean[x * 32:(x + 1
 late = np.argsort(mean)[-16:]
 print("  16 latest blocks on average:", sorted(int(b) for b in late), "their mean", round(float(mean[late].mean()), 1),
       "all-block mean", round(float(mean.mean()), 1), "max of per-run last", round(float(runs.max(axis=1).mean()), 1))
+# the select kernel behind it (same clock): phases of its thread 0, relative to the scan's first block start and to its own start
+k4 = np.zeros(16, dtype=np.int64)
+if hasattr(lib, "lbh_debug_k4_times"):
+    acc = []
+    for _ in range(8):
+        ix.search_shard(q, 8, _hip.SINCE_NONE, 0, st)
+        lib.lbh_debug_k2_times(out.ctypes.data_as(ctypes.c_void_p))
+        lib.lbh_debug_k4_times(k4.ctypes.data_as(ctypes.c_void_p))
+        r = out[:g].astype(np.float64) / 100.0
+        k = k4.astype(np.float64) / 100.0
+        acc.append(np.concatenate([[r[:, 5].max() - r[:, 0].min(), k[0] - r[:, 0].min()], k[[1, 2, 3, 4, 6, 7]] - k[0]]))
+    m = np.median(np.array(acc), axis=0)
+    print("  select kernel (medians of 8): last scan block written %.2f, select starts %.2f us after the scan's start;" % (m[0], m[1]))
+    print("    then +us: counters read %.2f, candidates cut %.2f, exact scores %.2f, sorted %.2f, result written %.2f, published %.2f"
+          % tuple(m[2:]))
+    print("    candidates in the flat list E = %d, kept for the exact re-rank M = %d (last search)" % (k4[8], k4[9]))
