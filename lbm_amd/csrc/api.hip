@@ -491,7 +491,7 @@ int run_page(lbh_index* ix, lbh_slot* sl, int page, int64_t since_ms, uint64_t t
         if (half && !emb16_current(ix)) return LBH_NEED_EMB16;
         if (fast)
             HIP_TRY(lbh_launch_search_fast(dv, half ? ix->emb16 : nullptr, sl->ws, sl->qptr, sl->qarg, page, has_since, since_ms,
-                                           tag_mask, half ? lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu, true) : grid, c->n_cu, c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, e0, e1));
+                                           tag_mask, (half && !has_since && !tag_mask) ? lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu, true) : grid, c->n_cu, c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, e0, e1));
         else {
             const int xgrid = std::min(grid, 512);
             HIP_TRY(lbh_launch_search_exact(dv, sl->ws, sl->qptr, sl->qarg, page, has_since, since_ms, tag_mask, cur, xgrid, seq, s, e0, e1));
@@ -1585,7 +1585,7 @@ int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, i
             const bool half = c->scan_mode == 1 && nscale <= 1.001f && nscale >= 0.25f;
             if (half && !emb16_current(ix)) return LBH_NEED_EMB16;
             HIP_TRY(lbh_launch_search_fast(dv, half ? ix->emb16 : nullptr, sl->ws, nullptr, sl->qarg, page, has_since, since_ms, tag_mask,
-                                           half ? lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu, true) : grid,
+                                           (half && !has_since && !tag_mask) ? lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu, true) : grid,
                                            c->n_cu, c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, timing ? sl->ev[0] : nullptr,
                                            timing ? sl->ev[1] : nullptr, &xc));
             lbh_cursor cur;

@@ -179,7 +179,7 @@ hipError_t lbh_launch_iota_u64(uint64_t* dst, uint64_t first, int64_t n, hipStre
 hipError_t lbh_launch_bswap_u64(uint64_t* p, int64_t n, hipStream_t s);
 hipError_t lbh_launch_scatter_u64(uint64_t* dst, const int64_t* rows_dev, const uint64_t* vals_dev, int64_t n, hipStream_t s);
 // search.hip
-int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu, bool half = false);
+int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu, bool half = false);  // half: the unfiltered fp16 scan
 // emb16: NULL = scan the fp32 matrix; else the fp16 copy (opt-in scan_mode 1; `margin` must then be the fp16 one)
 hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, const double* qptr,
                                   const lbh_qarg& qa, int k, int has_since,

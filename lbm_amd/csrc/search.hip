@@ -2179,8 +2179,10 @@ int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu, bool half) {
     // 24.8 -> 23.2, 100 k: 16.2 -> 14.4): half as many block epilogues and candidate lists, and the streaming loop has too
     // few tiles per wave for a second block to hide anything.  From ~3 M rows on two blocks per CU win by 1-3 %
     // (tools/scripts/scan_block_sweep.sh; 512-thread blocks were measured too: within noise of these two).
-    // The fp16 flavour (half as many bytes per tile) is faster with one block per CU at every size measured (10 M rows:
-    // 189.4 against 195.2 us, 1 M: 32.7 against 39.3; tools/scripts/scan_split_ab_fp16.sh).
+    // `half`: the UNFILTERED fp16 flavour (half as many bytes per tile) is faster with one block per CU at every size
+    // measured (10 M rows: 189.4 against 195.2 us, 100 M: 1749 against 1820; tools/scripts/scan_split_ab_fp16.sh).  With a
+    // since / tag mask its extra per-row loads want the second block's waves to hide behind (100 M rows, since filter:
+    // 2148 us with one block per CU, 1921 with two), so the callers ask for this only without filters.
     if (blocks_per_cu <= 0) blocks_per_cu = (half || n_rows <= 2000000) ? 1 : 2;
     const int64_t tiles = (n_rows + 63) / 64;
     int64_t blocks = (tiles + LBH_SCAN_WAVES - 1) / LBH_SCAN_WAVES;
