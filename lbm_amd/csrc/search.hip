@@ -645,6 +645,9 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
         __syncthreads();
         M = sh_cnt;
     } else if (E <= 2 * LBH_MCAP) {
+        // (Tried instead for k <= 16: every wave sorts a 1/16 slice in registers, wave 0 merges the slices' k best.  Two
+        // barriers instead of the radix passes, but 16 waves of cross-lane sorts at once took 13.3 us against this
+        // path's 6.9 for 1 200-2 000 entries -- dropped.)
         // the usual single-query case (512 blocks x k candidates): ONE pass over the global list into LDS; the
         // min/max pass, the digit passes and the cut then read LDS (each global pass cost 1-2 us of L2 latency)
         for (int e = tid; e < E; e += SEL_THREADS) sbuf[e] = cand[e];
