@@ -83,7 +83,8 @@ int lbh_device_name(lbh_ctx* ctx, char* buf, int buflen);
  * re-rank is always exact fp64), "bq_mode" (batched scan precision: 0 fp32 MFMA, 1 split bf16,
  * 2 fp16 = default), "spin_us" (completion-ticket polling budget).  Also read from the
  * environment at lbh_init as LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT / LBH_SCAN_MODE /
- * LBH_BQ_MODE / LBH_SPIN_US. */
+ * LBH_BQ_MODE / LBH_SPIN_US; environment only: LBH_SCAN_SPLIT ("a,b,c,d": tile shares of the scan's
+ * four block classes, "0": grid-stride loop). */
 int lbh_set_option(lbh_ctx* ctx, const char* name, int64_t value);
 
 /* Pinned (page-locked) host memory for the arrays handed to lbh_index_add / lbh_embed_batch (no reference counterpart:
