@@ -1,4 +1,6 @@
 #!/bin/bash
+# (Record of a dropped experiment: the LBH_MSGR_* switches lived in the messenger-wave patch of search.hip, which was not
+# kept -- see DESIGN.md, K2, item (g).)
 # Which part of the messenger-wave build slows the streaming loop?  _a: messenger leaves at once; _b: streaming waves skip
 # their LDS publication (messenger then leaves when wave 0 ends); _c: both.  One box.
 for v in "" _a _b _c; do
