@@ -293,7 +293,7 @@ def test_randomised_incremental_ops_vs_oracle(hip, seed, hex_hashes, smode):
             for h in list(og._embedding_cache)[:3]:
                 assert hexes(g._embedding_cache[h]) == hexes(og._embedding_cache[h]), (step, h)
     hip.set_option("scan_mode", 0)
-    assert n_queries > 100
+    assert n_queries > 60  # ~119 expected (17 % of 700 steps); a floor, not a distribution test
 
 
 def test_queries_overlap_publishes_from_another_thread(hip):
