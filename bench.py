@@ -184,14 +184,18 @@ def main():
     rehearse = os.environ.get("LBM_BENCH_REHEARSE_GLOO") == "1"
     if rehearse:
         local_rank = 0
-    os.environ.setdefault("LBM_HIP_DEVICE", str(local_rank))
+    device = local_rank  # LB_HIP_DEVICES ("0,1,2,3": rank LOCAL_RANK takes that entry) wins, as in lbm_amd._hip.default_device
+    listed = [x.strip() for x in os.environ.get("LB_HIP_DEVICES", "").split(",") if x.strip()]
+    if local_rank < len(listed):
+        device = int(listed[local_rank])
+    os.environ.setdefault("LBM_HIP_DEVICE", str(device))
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
     import torch
     import torch.distributed as dist
     have_gpu = torch.cuda.is_available()  # False only in the CPU rehearsal of the launcher (tests/bench_cpu_harness.py)
     if have_gpu or not rehearse:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(device)
     coll_dev = "cpu"
     if world > 1:
         # torch.distributed is plumbing only (rendezvous, barriers, the max / sum of the timing scalars), over gloo on the
