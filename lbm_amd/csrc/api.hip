@@ -9,6 +9,7 @@
 #include <cstring>
 #include <chrono>
 #include <dlfcn.h>
+#include <exception>
 #include <condition_variable>
 #include <mutex>
 #include <shared_mutex>
@@ -19,7 +20,8 @@
 #include "lbh_internal.h"
 
 // No exception may cross the C ABI: entry points that grow host containers are function-try-blocks ending in this.
-#define LBH_CATCH_ALLOC catch (const std::bad_alloc&) { return fail(LBH_E_NOMEM, "out of host memory"); }
+#define LBH_CATCH_ALLOC catch (const std::bad_alloc&) { return fail(LBH_E_NOMEM, "out of host memory"); } \
+    catch (const std::exception& e) { return fail(LBH_E_INTERNAL, "%s", e.what()); }
 
 namespace {
 
