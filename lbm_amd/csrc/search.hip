@@ -2178,7 +2178,9 @@ hipError_t lbh_launch_recent(const int64_t* created, const uint64_t* order, int6
 }
 
 int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu, bool half) {
-    // blocks_per_cu <= 0: by size.  Up to ~2 M rows ONE 4-wave block per CU is faster (1 M rows: scan 56 -> 50 us, 300 k:
+    // blocks_per_cu <= 0: by size.  (Re-measured with the contiguous tile ranges: 2.5 M rows 101 us with one block per CU
+    // against 108 with two, 3.5 M 144 / 154 (whole query 175 / 180), 4 M 157.6 / 156.9 (whole query 189 / 182) -- the switch
+    // sits at 3.5 M.)  Up to ~3.5 M rows ONE 4-wave block per CU is faster (1 M rows: scan 56 -> 50 us, 300 k:
     // 24.8 -> 23.2, 100 k: 16.2 -> 14.4): half as many block epilogues and candidate lists, and the streaming loop has too
     // few tiles per wave for a second block to hide anything.  From ~3 M rows on two blocks per CU win by 1-3 %
     // (tools/scripts/scan_block_sweep.sh; 512-thread blocks were measured too: within noise of these two).
@@ -2186,7 +2188,7 @@ int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu, bool half) {
     // measured (10 M rows: 189.4 against 195.2 us, 100 M: 1749 against 1820; tools/scripts/scan_split_ab_fp16.sh).  With a
     // since / tag mask its extra per-row loads want the second block's waves to hide behind (100 M rows, since filter:
     // 2148 us with one block per CU, 1921 with two), so the callers ask for this only without filters.
-    if (blocks_per_cu <= 0) blocks_per_cu = (half || n_rows <= 2000000) ? 1 : 2;
+    if (blocks_per_cu <= 0) blocks_per_cu = (half || n_rows <= 3500000) ? 1 : 2;
     const int64_t tiles = (n_rows + 63) / 64;
     int64_t blocks = (tiles + LBH_SCAN_WAVES - 1) / LBH_SCAN_WAVES;
     const int64_t cap = (int64_t)n_cu * blocks_per_cu < LBH_MAX_BLOCKS ? (int64_t)n_cu * blocks_per_cu : LBH_MAX_BLOCKS;

@@ -1,7 +1,7 @@
 """Every 64-row tile of the matrix is scanned exactly once, whatever way the single-query scan divides the tiles
 among its blocks (contiguous weighted ranges, `lbh_split` in lbm_amd/csrc/search.hip, or the grid-stride loop below
 two tiles per wave).  Sizes sit on the switches: grid-stride <-> ranges (2 x 256 blocks x 4 waves = 2 048 tiles =
-131 072 rows on a 256-CU part), one <-> two blocks per CU (2 000 000 rows), ragged last tiles.
+131 072 rows on a 256-CU part), one <-> two blocks per CU (3 500 000 rows), ragged last tiles.
 
 Method: one "needle" row per tile, at a random position inside it, equal to one of the query vectors (score exactly
 1.0, far above the 0.01-norm background); tile t belongs to query t mod nq, nq chosen so that a query owns at most
@@ -12,7 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SIZES = [131_007, 131_072, 131_073, 131_136, 262_207, 1_000_017, 2_000_000, 2_000_001, 2_000_127]
+SIZES = [131_007, 131_072, 131_073, 131_136, 262_207, 1_000_017, 3_500_000, 3_500_001, 3_500_127]
 
 
 @pytest.mark.parametrize("n", SIZES)

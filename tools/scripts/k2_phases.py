@@ -21,7 +21,7 @@ for _ in range(5):
     ix.search_shard(q, 8, _hip.SINCE_NONE, 0, st)
 out = np.zeros((2048, 6), dtype=np.int64)
 lib.lbh_debug_k2_times(out.ctypes.data_as(ctypes.c_void_p))
-g = int(os.environ.get("K2_BLOCKS", "0")) or min(256 if n <= 2_000_000 else 512, (n + 255) // 256)
+g = int(os.environ.get("K2_BLOCKS", "0")) or min(256 if n <= 3_500_000 else 512, (n + 255) // 256)
 t = out[:g].astype(np.float64) / 100.0  # us
 t0 = t[:, 0].min()
 names = ["start", "loop done", "wave compact", "barrier", "sorted+cut", "written"]
