@@ -476,19 +476,18 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
 constexpr int SEL_THREADS = 1024;
 constexpr int LBH_SORT_ALL = 1024;  // select_fast_body: candidate lists up to this size are sorted whole
 constexpr int LBH_RANK_ALL = 768;   // ... and up to this size the k-th best is found by rank counting, without a sort
+constexpr int LBH_SEL_REGS = 24;    // ... and up to 24 x 1024 entries the scores are selected from registers (28 spills under the 1024-thread bound)
 
-template <class F>
-__device__ uint64_t block_radix_select(int E, int nbytes, int64_t krem, F val, int* hist, int64_t* sh_krem,
-                                       int* sh_bin) {
+// Core: `each(body)` calls body(v) for every value of the calling thread that is in play (the values may sit in global
+// memory, in LDS or in registers).
+template <class Each>
+__device__ uint64_t block_radix_select_each(int nbytes, int64_t krem, Each each, int* hist, int64_t* sh_krem, int* sh_bin) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // value range first: digits are taken from (v - lo), so clustered values (scores share their high
     // bits) spread over the bins instead of serialising every LDS atomic on one bin
     __shared__ uint64_t sh_lo[SEL_THREADS / 64], sh_hi[SEL_THREADS / 64];
     uint64_t lo = ~0ull, hi = 0;
-    for (int e = tid; e < E; e += SEL_THREADS) {
-        uint64_t v;
-        if (val(e, &v)) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
-    }
+    each([&](uint64_t v) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; });
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const uint64_t l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
@@ -508,10 +507,9 @@ __device__ uint64_t block_radix_select(int E, int nbytes, int64_t krem, F val, i
     for (int b = nbytes - 1; b >= 0; --b) {
         for (int t = tid; t < 256; t += SEL_THREADS) hist[t] = 0;
         __syncthreads();
-        for (int e = tid; e < E; e += SEL_THREADS) {
-            uint64_t v;
-            if (val(e, &v) && ((v - lo) & pmask) == prefix) atomicAdd(&hist[(int)(((v - lo) >> (8 * b)) & 255)], 1);
-        }
+        each([&](uint64_t v) {
+            if (((v - lo) & pmask) == prefix) atomicAdd(&hist[(int)(((v - lo) >> (8 * b)) & 255)], 1);
+        });
         __syncthreads();
         if (wave == 0) {  // wave-parallel search for the bin holding the krem-th largest value
             const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
@@ -541,6 +539,19 @@ __device__ uint64_t block_radix_select(int E, int nbytes, int64_t krem, F val, i
         __syncthreads();
     }
     return prefix + lo;
+}
+
+// The same over E indexed entries: val(e, &v) says whether entry e is in play and yields its value.
+template <class F>
+__device__ uint64_t block_radix_select(int E, int nbytes, int64_t krem, F val, int* hist, int64_t* sh_krem,
+                                       int* sh_bin) {
+    auto each = [&](auto body) {
+        for (int e = threadIdx.x; e < E; e += SEL_THREADS) {
+            uint64_t v;
+            if (val(e, &v)) body(v);
+        }
+    };
+    return block_radix_select_each(nbytes, krem, each, hist, sh_krem, sh_bin);
 }
 
 // shared tail of both final kernels: rows xr[0..M) (+ ord64 scores xo when have_scores) -> exact
@@ -670,6 +681,35 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
 #pragma unroll
         for (int i = 0; i < 2 * LBH_MCAP / SEL_THREADS; ++i) {
             if (tid + i * SEL_THREADS < E && (uint32_t)(mine[i] >> 32) >= thr) sbuf[atomicAdd(&sh_cnt, 1)] = mine[i];
+        }
+        __syncthreads();
+        M = sh_cnt;
+    } else if (E <= LBH_SEL_REGS * SEL_THREADS) {
+        // A long list (top_k 64: ~16 000-23 000 entries from 256-512 blocks; beyond 24 576 the path below): every thread takes the scores of its
+        // entries into REGISTERS with one batch of independent loads; the min/max pass, the digit passes and the cut then
+        // run without touching global memory (five passes over the global list cost 25 of this kernel's 41 us).
+        uint32_t sv[LBH_SEL_REGS];
+#pragma unroll
+        for (int i = 0; i < LBH_SEL_REGS; ++i) {
+            const int e = tid + i * SEL_THREADS;
+            sv[i] = e < E ? (uint32_t)(cand[e] >> 32) : 0u;
+        }
+        if (E >= k) {
+            auto each = [&](auto body) {
+#pragma unroll
+                for (int i = 0; i < LBH_SEL_REGS; ++i)
+                    if (tid + i * SEL_THREADS < E) body((uint64_t)sv[i]);
+            };
+            const uint32_t kth = (uint32_t)block_radix_select_each(4, k, each, hist, &sh_krem, &sh_bin);
+            thr = lbh_ord32(lbh_unord32(kth) - margin);
+        }
+#pragma unroll
+        for (int i = 0; i < LBH_SEL_REGS; ++i) {
+            const int e = tid + i * SEL_THREADS;
+            if (e < E && sv[i] >= thr) {  // the row comes from the list again, for the few survivors only
+                const int pos = atomicAdd(&sh_cnt, 1);
+                if (pos < 2 * LBH_MCAP) sbuf[pos] = cand[e];
+            }
         }
         __syncthreads();
         M = sh_cnt;

@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from lbm_amd import _hip
 lib = ctypes.CDLL(os.environ["LBM_HIP_LIB"])
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+TOPK = int(os.environ.get("K2_TOPK", "8"))
 rng = np.random.default_rng(0)
 ix = _hip.Index()
 for s in range(0, n, 1_000_000):
@@ -18,7 +19,7 @@ for s in range(0, n, 1_000_000):
 q = rng.standard_normal(64); q /= np.linalg.norm(q)
 st = _hip.Stats(); st.want_timing = 1
 for _ in range(5):
-    ix.search_shard(q, 8, _hip.SINCE_NONE, 0, st)
+    ix.search_shard(q, TOPK, _hip.SINCE_NONE, 0, st)
 out = np.zeros((2048, 6), dtype=np.int64)
 lib.lbh_debug_k2_times(out.ctypes.data_as(ctypes.c_void_p))
 g = int(os.environ.get("K2_BLOCKS", "0")) or min(256 if n <= 3_500_000 else 512, (n + 255) // 256)
@@ -37,7 +38,7 @@ print("  per-block phase medians (us):", {names[i + 1]: round(float(np.median(d[
 # from run to run and their mean by blockIdx % 8 (the XCD a block is dispatched to).
 runs = []
 for _ in range(8):
-    ix.search_shard(q, 8, _hip.SINCE_NONE, 0, st)
+    ix.search_shard(q, TOPK, _hip.SINCE_NONE, 0, st)
     lib.lbh_debug_k2_times(out.ctypes.data_as(ctypes.c_void_p))
     r = out[:g].astype(np.float64) / 100.0
     runs.append(r[:, 1] - r[:, 0].min())
@@ -55,7 +56,7 @@ k4 = np.zeros(16, dtype=np.int64)
 if hasattr(lib, "lbh_debug_k4_times"):
     acc = []
     for _ in range(8):
-        ix.search_shard(q, 8, _hip.SINCE_NONE, 0, st)
+        ix.search_shard(q, TOPK, _hip.SINCE_NONE, 0, st)
         lib.lbh_debug_k2_times(out.ctypes.data_as(ctypes.c_void_p))
         lib.lbh_debug_k4_times(k4.ctypes.data_as(ctypes.c_void_p))
         r = out[:g].astype(np.float64) / 100.0
