@@ -21,6 +21,14 @@ Launching: ``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the envi
 (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``) each process is one rank.  Either way
 the run fails if the number of ranks is not ``--gpus``.
 
+``--scaling strong`` keeps the TOTAL corpus fixed (``--claims`` claims dealt out in N contiguous parts); the default,
+``weak``, gives every GPU ``--claims`` claims.  The printed line says which (``scaling``, ``config.workload``).
+
+``latency_ms`` carries two pairs: ``p50`` / ``p99`` time the ranking call on a query VECTOR (lbh_index_search_shard, the
+step that ``value`` counts), ``compile_context_p50`` / ``_p99`` time what the metric names -- query TEXT in, context
+TEXT out: embed(query) on the GPU (K1) + scan (K2) + select / exact re-rank (K4) in one stream-ordered call
+(lbh_index_search_text), then claim id -> hash and the formatting of lb/context_graph.py:122-133 for the k winners.
+
 LBM_BENCH_REHEARSE_GLOO=1 rehearses the N > 1 flow on a box with fewer GPUs than ranks (see main()).
 """
 from __future__ import annotations
@@ -46,7 +54,11 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
-    p.add_argument("--claims", type=int, default=10_000_000, help="claims per GPU")
+    p.add_argument("--claims", type=int, default=10_000_000,
+                   help="claims per GPU (--scaling weak, the default) or in total, split over the GPUs (--scaling strong)")
+    p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                   help="weak: every GPU holds --claims claims; strong: --claims is the whole corpus, dealt out in N contiguous parts")
+    p.add_argument("--cc-steps", type=int, default=200, help="timed compile_context calls (text in, context text out) of the latency leg, N = 1")
     p.add_argument("--top-k", type=int, default=8)
     p.add_argument("--since", choices=["none", "p50", "p90"], default="none")
     p.add_argument("--queries", type=int, default=64)
@@ -134,6 +146,87 @@ def cpu_baseline(sample_claims: int, top_k: int):
     }
 
 
+VALU_ISSUE_PER_S = 256 * 4 * 2.4e9 / 2  # wave-instructions/s: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md)
+PCIE_GBS = 57.0                         # pinned H2D rate measured on the pool's boxes (tools/h2d_rate.py)
+
+
+def vectorise_roofline(k1, claims, t_add, t_add_first, chunk, n_chunks):
+    """K1 (embed_kernel) is bound by VALU issue, not by HBM: its achieved fraction is wave-instructions per claim (from
+    the committed counter pass, profiles/r*_pmc_k1.json: SQ_INSTS_VALU per claim of this very corpus) x claims/s of the
+    kernel alone (text resident in HBM, measured here) / the chip's VALU issue rate.  The ingest call (text + metadata
+    from pinned host buffers) is priced against PCIe; HBM traffic (text in + 768 B out per claim) is given for scale."""
+    if not k1:
+        return None
+    out = {"bound": "valu-issue", "kernel": "embed_kernel", "kernel_claims_per_s": k1["claims"] / k1["seconds"],
+           "kernel_ms_per_million_claims": k1["seconds"] / k1["claims"] * 1e9,
+           "peak": VALU_ISSUE_PER_S, "unit": "wave-instructions/s"}
+    try:
+        import glob
+        pmc = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_k1.json")))
+        with open(pmc[-1]) as f:
+            per_claim = float(json.load(f)["embed_kernel"]["valu_wave_instructions_per_claim"])
+        out["valu_wave_instructions_per_claim"] = per_claim
+        out["instructions_source"] = f"profiles/{os.path.basename(pmc[-1])} (SQ_INSTS_VALU / claims, same corpus); not measured in this run"
+        out["achieved"] = per_claim * out["kernel_claims_per_s"]
+        out["frac"] = out["achieved"] / VALU_ISSUE_PER_S
+    except Exception:
+        out["achieved"] = out["frac"] = None
+    bytes_per_claim_hbm = k1["text_bytes"] / k1["claims"] + 8 + 768
+    out["hbm_floor_claims_per_s"] = HBM_PEAK_GBS * 1e9 / bytes_per_claim_hbm
+    bytes_per_claim_pcie = k1["text_bytes"] / k1["claims"] + 8 + 48  # text + offset + created / tags / key
+    out["pcie_floor_claims_per_s"] = PCIE_GBS * 1e9 / bytes_per_claim_pcie
+    steady = (claims - min(chunk, claims)) / (t_add - t_add_first) if n_chunks > 1 and t_add > t_add_first else None
+    out["ingest_claims_per_s_steady"] = steady
+    out["ingest_frac_of_pcie_floor"] = steady / out["pcie_floor_claims_per_s"] if steady else None
+    return out
+
+
+def bring_up_rccl(_hip, dist, torch, rank: int, world: int):
+    """-> (Comm or None, reason, stuck).  Every step that can fail on ONE rank alone is agreed on over gloo BEFORE the
+    collective ncclCommInitRank, so that no rank waits inside it for a peer that has already given up:
+      1. every rank opens librccl and resolves its symbols locally (lbh_comm_unique_id does exactly that);
+      2. all-reduce(MIN) of the outcome -- if any rank cannot, nobody calls RCCL;
+      3. rank 0's id is broadcast, every rank calls Comm() (collective) -- in a helper thread with a deadline, because a
+         bring-up that never returns must end in the gloo fallback, not in a hung run;
+      4. all-reduce(MIN) of that outcome.  On a timeout the helper thread is abandoned (``stuck``): the process then
+         leaves through os._exit at the end instead of joining it."""
+    import threading
+    err = ""
+    try:
+        my_id = _hip.comm_unique_id()  # dlopen + dlsym + ncclGetUniqueId: local, no peer involved
+    except _hip.HipBackendError as e:
+        my_id, err = b"", str(e)
+    ok = torch.tensor([1 if my_id else 0], dtype=torch.int64)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        return None, err or "another rank cannot open librccl", False
+    uid = [my_id if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    box = {}
+
+    def init():
+        try:
+            box["comm"] = _hip.Comm(uid[0], rank, world)  # collective: RCCL communicator over the node's xGMI links
+        except Exception as e:  # noqa: BLE001
+            box["err"] = str(e)
+
+    t = threading.Thread(target=init, daemon=True)
+    t.start()
+    t.join(float(os.environ.get("LBM_COMM_INIT_TIMEOUT_S", "180")))
+    stuck = t.is_alive()
+    comm = None if stuck else box.get("comm")
+    ok = torch.tensor([1 if comm is not None else 0, 1 if stuck else 0], dtype=torch.int64)
+    flags = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(flags, ok)
+    all_ok = all(int(f[0]) == 1 for f in flags)
+    any_stuck = any(int(f[1]) == 1 for f in flags)
+    if all_ok:
+        return comm, "", False
+    # some rank failed or hangs: a communicator that did come up on this rank cannot be torn down collectively any more
+    why = box.get("err") or ("ncclCommInitRank did not return in time" if stuck else "another rank failed to join")
+    return None, why, True if (comm is not None or stuck or any_stuck) else False
+
+
 def launch_ranks(args) -> int:
     """``--gpus N`` without a launcher: start the N ranks as child processes (nothing in this process has touched a
     GPU), wait for all of them, fail if any fails.  Rank 0 prints the JSON line on the inherited stdout."""
@@ -208,59 +301,68 @@ def main():
     from lbm_amd.sharded import ShardedSearcher
 
     # ---- build this rank's shard in HBM (texts -> K1 on the GPU) -------------------------------
+    if args.scaling == "strong":  # the whole corpus is --claims claims; rank r takes the r-th contiguous part
+        first = args.claims * rank // world
+        my_claims = args.claims * (rank + 1) // world - first
+    else:
+        first, my_claims = rank * args.claims, args.claims
     ix = _hip.Index()
-    ix.reserve(args.claims)
+    ix.reserve(my_claims)
     chunk = 1_000_000
-    n_chunks = (args.claims + chunk - 1) // chunk
+    n_chunks = (my_claims + chunk - 1) // chunk
     t_gen = t_add = t_add_first = 0.0
-    created_p50 = created_p90 = None
     done = 0
+    # The chunk's arrays are generated straight into page-locked buffers (lbh_host_alloc), so the ingest call moves them
+    # by asynchronous DMA under K1 (DESIGN.md "Ingest path"); filling the buffers is part of the generation time.
+    pins = None
+    if have_gpu:
+        cap = min(chunk, max(my_claims, 1))
+        pins = {"blob": _hip.PinnedArray(cap * 175 + 64, np.uint8), "offsets": _hip.PinnedArray(cap + 1, np.int64),
+                "created": _hip.PinnedArray(cap, np.int64), "tags": _hip.PinnedArray(cap, np.uint64),
+                "keys": _hip.PinnedArray((cap, 32), np.uint8)}
+    host_chunks = []  # (blob, offsets, keys, tagmask) per chunk, kept on the host for the compile_context leg (N = 1 only)
     for ci in range(n_chunks):
-        m = min(chunk, args.claims - done)
+        m = min(chunk, my_claims - done)
         t0 = time.perf_counter()
-        ch = synth.make_chunk(rank * args.claims + done, m, seed=1234, chunk_index=rank * n_chunks + ci,
-                              real_sha_keys=False)
+        ch = synth.make_chunk(first + done, m, seed=1234, chunk_index=rank * 4096 + ci, real_sha_keys=False)  # chunk seeds never repeat across ranks
+        arrs = (ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)
+        if pins is not None and ch.blob.shape[0] <= pins["blob"].a.shape[0]:
+            nb = ch.blob.shape[0]
+            pins["blob"].a[:nb] = ch.blob
+            pins["offsets"].a[: m + 1] = ch.offsets
+            pins["created"].a[:m] = ch.created_ms
+            pins["tags"].a[:m] = ch.tagmask
+            pins["keys"].a[:m] = ch.keys
+            arrs = (pins["blob"].a[:nb], pins["offsets"].a[: m + 1], pins["created"].a[:m], pins["tags"].a[:m], pins["keys"].a[:m])
         t1 = time.perf_counter()
-        ids = ix.add_texts(ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)
+        ids = ix.add_texts(*arrs)
         ix.retract_many(ids[ch.retracted])  # 1 % of the claims: one compaction kernel per chunk
         t2 = time.perf_counter()
         t_gen += t1 - t0
         t_add += t2 - t1
         if ci == 0:
             t_add_first = t2 - t1  # carries the one-off costs: code object load, scratch and staging allocation
+        if world == 1:
+            host_chunks.append((ch.blob, ch.offsets, ch.keys, ch.tagmask))
         done += m
     live = ix.size()
-    base = synth.BASE_MS + 1000 * rank * args.claims
-    since = {"none": _hip.SINCE_NONE, "p50": base + 1000 * (args.claims // 2),
-             "p90": base + 1000 * (9 * args.claims // 10)}[args.since]
+    base = synth.BASE_MS + 1000 * first
+    since = {"none": _hip.SINCE_NONE, "p50": base + 1000 * (my_claims // 2),
+             "p90": base + 1000 * (9 * my_claims // 10)}[args.since]
 
     queries = synth.make_queries(args.queries, seed=4321)
     qvecs = _hip.embed_batch(queries)
     searcher = comm = None
     exchange_note = ""
+    comm_stuck = False
     if world > 1 and rehearse:
         searcher = ShardedSearcher(ix.search_shard, rank, world, device=None)
     elif world > 1:
-        comm_err = ""
-        try:
-            uid = [_hip.comm_unique_id() if rank == 0 else None]
-        except _hip.HipBackendError as e:  # librccl missing / unusable: every rank learns it through the broadcast
-            uid, comm_err = [b""], str(e)
-        dist.broadcast_object_list(uid, src=0)
-        if uid[0]:
-            try:
-                comm = _hip.Comm(uid[0], rank, world)  # collective: RCCL communicator over the node's xGMI links
-            except _hip.HipBackendError as e:
-                comm_err = str(e)
-        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
+        comm, comm_err, comm_stuck = bring_up_rccl(_hip, dist, torch, rank, world)
+        if comm is None:
             # RCCL could not be brought up on every rank: the run still measures the sharded search, with the lists
             # travelling over gloo instead (said so on the printed line); never silently
-            if comm is not None:
-                comm.close()
-                comm = None
-            exchange_note = "RCCL unavailable (%s): lists gathered over gloo" % (comm_err or "another rank failed")
+            exchange_note = "RCCL unavailable (%s): lists gathered over gloo" % comm_err
             print(f"bench.py rank {rank}: {exchange_note}", file=sys.stderr)
             searcher = ShardedSearcher(ix.search_shard, rank, world, device=None)
     stats = _hip.Stats()
@@ -283,6 +385,22 @@ def main():
         if have_gpu:
             torch.cuda.synchronize()
 
+    if comm is not None:
+        # canary: the first all-gather over xGMI this communicator ever carries.  Its outcome is agreed on over gloo, so
+        # a data path that does not work (error, or the library's bounded wait running out) ends in the gloo exchange on
+        # EVERY rank, said so on the printed line -- not in a hang and not in a half-failed run.
+        canary_err = ""
+        try:
+            step(0)
+        except _hip.HipBackendError as e:
+            canary_err = str(e)
+        ok = torch.tensor([0 if canary_err else 1], dtype=torch.int64)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            comm, comm_stuck = None, True  # never torn down: a collective may still be queued on it
+            exchange_note = "RCCL all-gather failed (%s): lists gathered over gloo" % (canary_err or "on another rank")
+            print(f"bench.py rank {rank}: {exchange_note}", file=sys.stderr)
+            searcher = ShardedSearcher(ix.search_shard, rank, world, device=None)
     for i in range(args.warmup):
         step(i)
     fence()
@@ -319,15 +437,67 @@ def main():
     else:
         n_timed = (args.steps + every - 1) // every
 
+    # ---- what the metric names: compile_context latency, query TEXT in -> context TEXT out (N = 1) ----------------
+    cc = None
+    if world == 1 and args.cc_steps > 0 and host_chunks:
+        from lbm_amd.context_graph import format_context
+
+        def claim(cid):  # claim id = position in the generated corpus (ids are handed out in insertion order)
+            blob, off, keys, tagmask = host_chunks[cid // chunk]
+            j = cid % chunk
+            m = int(tagmask[j])
+            return (bytes(keys[j]).hex(), bytes(blob[off[j]: off[j + 1]]).decode("ascii"),
+                    ["t%02d" % b for b in range(64) if (m >> b) & 1])
+
+        def compile_context(query):  # lb/node.py:718-734 -> lb/context_graph.py:104-133 on the HBM index
+            ids, _, _ = ix.search_text(query, args.top_k, since, 0)  # embed(query) + scan + exact top-k: one call, one wait
+            chosen = [claim(int(i)) for i in ids]
+            return format_context(query, [(t, tg) for _, t, tg in chosen]), [h for h, _, _ in chosen]
+
+        for i in range(min(args.warmup, 20)):
+            compile_context(queries[i % len(queries)])
+        cc_lat = []
+        for i in range(args.cc_steps):
+            s0 = time.perf_counter()
+            text, hashes = compile_context(queries[i % len(queries)])
+            cc_lat.append(time.perf_counter() - s0)
+        # the same answer as the vector entry the timed steps use (ids -> hashes), so both legs rank identically
+        ids0, _, keys0 = ix.search_shard(qvecs[(args.cc_steps - 1) % len(queries)], args.top_k, since, 0)
+        assert hashes == [bytes(k).hex() for k in keys0], "search_text and search_shard disagree"
+        cc = {"p50": float(np.percentile(cc_lat, 50) * 1e3), "p99": float(np.percentile(cc_lat, 99) * 1e3), "calls": args.cc_steps,
+              "context_bytes": len(text)}
+
+    # ---- K1 alone, text resident in HBM (vectorise.roofline) -------------------------------------------------------
+    k1 = None
+    if world == 1 and have_gpu and host_chunks:
+        blob, off = host_chunks[0][0], host_chunks[0][1]
+        m1 = off.shape[0] - 1
+        d_blob = torch.from_numpy(np.concatenate([blob, np.zeros(64, np.uint8)])).cuda()
+        d_off = torch.from_numpy(off).cuda()
+        d_e64 = torch.empty((m1, 64), dtype=torch.float64, device="cuda")
+        d_e32 = torch.empty((m1, 64), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(7):
+            s0 = time.perf_counter()
+            _hip.embed_batch_dev(d_blob.data_ptr(), d_off.data_ptr(), m1, int(off[-1]), d_e64.data_ptr(), d_e32.data_ptr())
+            ts.append(time.perf_counter() - s0)
+        t_k1 = float(np.median(ts[2:]))
+        k1 = {"claims": m1, "text_bytes": int(off[-1]), "seconds": t_k1}
+        del d_blob, d_off, d_e64, d_e32
+
     if rank == 0:
         bytes_per_row = 256 + (8 if args.since != "none" else 0)
-        traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/*pmc_scan.json), scaled to this row count
+        # HBM bytes per launch: NOT collected in this run (PMC passes need rocprofv3 around the process) -- the newest
+        # committed counter pass (profiles/*pmc_scan.json: FETCH_SIZE x 2 + WRITE_SIZE per row) scaled to this row count
+        traffic, traffic_source = None, None
         try:
             import glob
             pmc = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_scan.json")))
             if pmc and args.since == "none":
                 with open(pmc[-1]) as f:
                     traffic = json.load(f)["scan_f32_kernel"]["hbm_bytes_per_row"] * live
+                traffic_source = f"profiles/{os.path.basename(pmc[-1])} (committed rocprofv3 --pmc passes) x {live} live rows; not measured in this run"
         except Exception:
             traffic = None
         avg_scan_s = scan_ms / 1e3 / max(n_timed, 1)
@@ -338,27 +508,36 @@ def main():
             "unit": "claims/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32 scan + f64 exact re-rank",
             "data": "synthetic" if not rehearse else "synthetic; REHEARSAL (all ranks on one GPU, gloo): not a measurement",
-            "config": {"workload": f"{args.claims}-claim shard per GPU (synthetic Zipf corpus, 1% retracted), "
+            "config": {"workload": (f"{args.claims}-claim shard per GPU" if args.scaling == "weak" else
+                                    f"{args.claims}-claim corpus in total, split into {world} contiguous shards (strong scaling)")
+                                   + " (synthetic Zipf corpus, 1% retracted), "
                                    f"single-query compile_context ranking, top_k={args.top_k}, since_ms={args.since}",
-                       "claims_per_gpu": args.claims, "live_claims_total": total_live, "top_k": args.top_k,
+                       "claims_per_gpu": my_claims, "claims_total": args.claims * world if args.scaling == "weak" else args.claims,
+                       "live_claims_total": total_live, "top_k": args.top_k,
                        "parallelism": (f"claim-sharded x{world}, one RCCL all-gather of the per-GPU top-k lists per query (inside liblbhip), "
                                        "same-comparator merge" if comm is not None else
                                        f"claim-sharded x{world}, lists gathered over gloo ({exchange_note or 'rehearsal'})")
                        if world > 1 else "single GPU"},
-            "latency_ms": {"p50": float(np.percentile(lat, 50) * 1e3), "p99": float(np.percentile(lat, 99) * 1e3)},
+            "latency_ms": {"p50": float(np.percentile(lat, 50) * 1e3), "p99": float(np.percentile(lat, 99) * 1e3),
+                           "what": "p50/p99: the ranking call on a query vector (the timed step); compile_context_*: query text -> "
+                                   "embed on the GPU + scan + exact top-k (lbh_index_search_text) -> hashes + formatted context text",
+                           "compile_context_p50": cc["p50"] if cc else None, "compile_context_p99": cc["p99"] if cc else None,
+                           "compile_context_calls": cc["calls"] if cc else 0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": live * bytes_per_row, "kernel": "scan_f32_kernel",
                          "bytes_per_claim": bytes_per_row, "avg_kernel_us": avg_scan_s * 1e6,
                          "timed_launches": n_timed},
-            "vectorise": {"claims_per_s_incl_h2d": args.claims / t_add if t_add > 0 else None,
+            "vectorise": {"claims_per_s_incl_h2d": my_claims / t_add if t_add > 0 else None,
                           "claims_per_s_incl_h2d_after_first_chunk":
-                              (args.claims - min(chunk, args.claims)) / (t_add - t_add_first) if n_chunks > 1 else None,
+                              (my_claims - min(chunk, my_claims)) / (t_add - t_add_first) if n_chunks > 1 else None,
                           "first_chunk_s": t_add_first,
-                          "host_text_generation_s": t_gen},
+                          "source_buffers": "pinned (lbh_host_alloc)" if pins is not None else "pageable",
+                          "host_text_generation_s": t_gen,
+                          "roofline": vectorise_roofline(k1, my_claims, t_add, t_add_first, chunk, n_chunks)},
             "fp32_fallbacks": fallbacks, "avg_candidates": cands / max(args.steps, 1),
         }
         if world == 1:
@@ -393,6 +572,12 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.barrier()  # no rank tears its communicator down while another may still be inside a collective
+    if comm_stuck:
+        # a communicator that never came up everywhere (or a collective still queued on one): nothing to tear down in
+        # order -- leave without running destructors that would wait for it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     if comm is not None:
         comm.close()
     if world > 1:

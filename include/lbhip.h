@@ -81,7 +81,9 @@ int lbh_device_name(lbh_ctx* ctx, char* buf, int buflen);
  * matrix, 256 B/claim, default; 1 = scan a 128 B/claim fp16 copy that the index builds on first
  * use, wider candidate margin, unit-scale data only - results are the same either way, the
  * re-rank is always exact fp64), "bq_mode" (batched scan precision: 0 fp32 MFMA, 1 split bf16,
- * 2 fp16 = default), "spin_us" (completion-ticket polling budget).  Also read from the
+ * 2 fp16 = default), "spin_us" (completion-ticket polling budget), "coll_timeout_ms" (longest wait for a
+ * claim-sharded search's all-gather; also LBH_COLL_TIMEOUT_MS), "inject_fault" (test hook, one-shot: 1 = the next
+ * sharded search's local part fails on this rank, 2 = its stream is held up past the timeout).  Also read from the
  * environment at lbh_init as LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT / LBH_SCAN_MODE /
  * LBH_BQ_MODE / LBH_SPIN_US; environment only: LBH_SCAN_SPLIT ("a,b,c,d": tile shares of the scan's
  * four block classes, "0": grid-stride loop). */
@@ -176,9 +178,11 @@ int lbh_index_search_shard(lbh_index* idx, const double* q_f64, int64_t k, int64
                            uint64_t* out_ids, double* out_scores, uint8_t* out_keys, int64_t* out_count,
                            lbh_stats* stats);
 
-/* No counterpart in the reference.  For callers that cannot allocate device memory -- code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc: a variant of lbh_index_search_shard that calls no hipMalloc / hipFree /
- * allocating routine at all.  The caller owns the claim arrays (device pointers, the index's layout: emb32 = n x 64
+/* No counterpart in the reference.  For callers that cannot allocate device memory -- tight serving loops, harnesses that
+ * forbid hipMalloc, code that runs between the captures of a HIP graph (the call itself cannot be captured: it runs on the
+ * library's own stream and ends in a hipStreamSynchronize): a variant of lbh_index_search_shard that calls no hipMalloc /
+ * hipFree / allocating routine at all.  The call is NOT ordered against any other stream: inputs must be complete, and
+ * the output buffers idle, on every stream of the caller's before it is made.  The caller owns the claim arrays (device pointers, the index's layout: emb32 = n x 64
  * floats, exactly (float) of emb64 = n x 64 doubles; created_ms / tagmask = n words, needed only when the filter is
  * used; keywords = n x 4 uint64, word w = the big-endian value of key bytes 8w..8w+7) and the outputs (device
  * pointers: out_rows = row indices, out_scores, each k entries; *out_count = number of results, or -1 if more than 2048
@@ -217,6 +221,27 @@ int lbh_comm_destroy(lbh_comm* comm);
 int lbh_index_search_sharded(lbh_index* idx, lbh_comm* comm, const double* q_f64, int64_t k, int64_t since_ms,
                              uint64_t tag_mask, uint64_t gid_mul, uint64_t gid_add, uint64_t* out_gids, double* out_scores,
                              uint8_t* out_keys, int64_t* out_count, lbh_stats* stats);
+
+/* Batched form (config 3 x config 4: many queries over a claim-sharded corpus; the reference's semantics per query are
+ * lb/context_graph.py:104-121, as for lbh_index_search).  Every rank, same queries / k / filters (collective): the local
+ * part is lbh_index_search on this rank's shard -- three or more queries share ONE pass over the shard on the matrix
+ * cores -- then ONE all-gather of the nq lists of (k + 1) x 48 bytes per rank and nq merges with the reference's
+ * comparator.  Outputs as lbh_index_search (row q at q * k), global ids as lbh_index_search_sharded, out_keys = nq x k x 32
+ * bytes or NULL.  Any k (the local search pages internally); nq x (k + 1) x 48 bytes <= 1 GiB.
+ *
+ * Failure containment (both sharded searches).  A rank whose LOCAL search fails still takes part in the all-gather: its
+ * list's count word carries the negative error code, and every rank returns an error for that call -- nobody is left
+ * waiting.  A rank that cannot reach the all-gather at all (it died) is noticed by its peers' bounded wait: after
+ * "coll_timeout_ms" (lbh_set_option / LBH_COLL_TIMEOUT_MS, default 60 000) the call fails with LBH_E_DEVICE and the
+ * communicator refuses further calls; the process should then exit (its stream still holds the unfinished collective). */
+int lbh_index_search_sharded_many(lbh_index* idx, lbh_comm* comm, const double* q_f64, int64_t nq, int64_t k, int64_t since_ms,
+                                  uint64_t tag_mask, uint64_t gid_mul, uint64_t gid_add, uint64_t* out_gids, double* out_scores,
+                                  uint8_t* out_keys, int64_t* out_counts, lbh_stats* stats);
+
+/* Plain all-gather of `bytes` bytes per rank through the communicator (host buffers in and out; recv = world x bytes,
+ * rank-major): what the claim-sharded graph uses to hand the winners' text and tags (lb/context_graph.py:122-133 formats
+ * them) from the owning rank to every rank.  Collective; same bounded wait as the searches. */
+int lbh_comm_allgather(lbh_comm* comm, const void* send, int64_t bytes, void* recv);
 
 /* Merge step of the claim-sharded search (host code, needs no GPU): `lists` = n_lists blocks of (k + 1) x 6
  * int64, as exchanged by the all-gather -- row 0 word 0 = entry count (<= k), rows 1.. = {fp64 score bits,

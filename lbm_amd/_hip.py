@@ -35,6 +35,7 @@ EXPORTS = [
     "lbh_index_search", "lbh_index_search_text", "lbh_index_search_shard",
     "lbh_index_recent", "lbh_index_set_order", "lbh_merge_topk", "lbh_search_dev_noalloc",
     "lbh_comm_unique_id", "lbh_comm_init", "lbh_comm_destroy", "lbh_index_search_sharded",
+    "lbh_index_search_sharded_many", "lbh_comm_allgather",
 ]
 
 
@@ -144,6 +145,9 @@ def load_library() -> ctypes.CDLL:
         L.lbh_comm_destroy.argtypes = [_vp]
         L.lbh_index_search_sharded.argtypes = [_vp, _vp, _vp, _i64, _i64, _u64, _u64, _u64, _vp, _vp, _vp, ctypes.POINTER(_i64),
                                                ctypes.POINTER(Stats)]
+        L.lbh_index_search_sharded_many.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _u64, _u64, _u64, _vp, _vp, _vp, _vp,
+                                                    ctypes.POINTER(Stats)]
+        L.lbh_comm_allgather.argtypes = [_vp, _vp, _i64, _vp]
         for name in EXPORTS:
             if name not in ("lbh_last_error", "lbh_version"):
                 getattr(L, name).restype = ctypes.c_int
@@ -350,6 +354,22 @@ class Comm:
         _check(self._L.lbh_comm_init(context(), ctypes.c_char_p(uid), self.rank, self.world, ctypes.byref(h)))
         self._h = h
 
+    def allgather(self, payload: bytes) -> list:
+        """Every rank's ``payload`` (any length), rank-major, through the communicator: one all-gather of the lengths,
+        one of the payloads padded to the longest (``lbh_comm_allgather``).  Collective."""
+        W = self.world
+        mine = np.array([len(payload)], dtype=np.int64)
+        sizes = np.zeros(W, dtype=np.int64)
+        _check(self._L.lbh_comm_allgather(self._h, _ptr(mine), 8, _ptr(sizes)))
+        width = int(sizes.max())
+        if width == 0:
+            return [b""] * W
+        send = np.zeros(width, dtype=np.uint8)
+        send[:len(payload)] = np.frombuffer(payload, dtype=np.uint8)
+        recv = np.zeros(W * width, dtype=np.uint8)
+        _check(self._L.lbh_comm_allgather(self._h, _ptr(send), width, _ptr(recv)))
+        return [recv[r * width: r * width + int(sizes[r])].tobytes() for r in range(W)]
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             self._L.lbh_comm_destroy(self._h)
@@ -514,6 +534,24 @@ class Index:
                                                 p_ids, p_sc, p_keys, p_cnt, ctypes.byref(stats) if stats is not None else None))
         n = cnt.value
         return ids[:n].copy(), sc[:n].copy(), keys[:n].copy()
+
+    def search_sharded_many(self, comm: "Comm", q: np.ndarray, k: int, since_ms: int = SINCE_NONE, tag_mask: int = 0,
+                            stats: Optional[Stats] = None, gid_mul: Optional[int] = None, gid_add: Optional[int] = None):
+        """Collective over ``comm``: the global top-k of every query of a batch (local K3 pass on each rank's shard, ONE
+        all-gather, nq merges) -> (global ids [nq, k], scores [nq, k], keys [nq, k, 32], counts [nq])."""
+        q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1, DIM)
+        nq, k = q.shape[0], max(0, int(k))
+        mul = comm.world if gid_mul is None else int(gid_mul)
+        add = comm.rank if gid_add is None else int(gid_add)
+        kk = max(k, 1)
+        ids = np.zeros((nq, kk), dtype=np.uint64)
+        sc = np.zeros((nq, kk), dtype=np.float64)
+        keys = np.zeros((nq, kk, KEY_BYTES), dtype=np.uint8)
+        cnt = np.zeros(max(nq, 1), dtype=np.int64)
+        _check(self._L.lbh_index_search_sharded_many(self._h, comm._h, _ptr(q), nq, k, _since(since_ms), int(tag_mask), mul, add,
+                                                     _ptr(ids), _ptr(sc), _ptr(keys), _ptr(cnt),
+                                                     ctypes.byref(stats) if stats is not None else None))
+        return ids[:, :k], sc[:, :k], keys[:, :k], cnt[:nq]
 
     def _out_bufs(self, k: int):
         """Output arrays and their ctypes pointers, kept per thread and per k (building them costs more than the call)."""

@@ -28,8 +28,9 @@ How the mirror works
            use "old", "new", "h1"): the UTF-8 bytes, zero-padded (UTF-8 byte order ==
            code-point order, and without NUL the padding cannot tie two hashes);
     "rank" anything else, or a mix: hashes are ranked with Python's own ``str``
-           order and the ranks become the keys (rewritten after every change:
-           O(n log n) host work per sync, see INTEGRATION.md Limits).
+           order and the ranks become the keys: 256-bit integers, a new hash takes the
+           midpoint of its neighbours' keys (O(log n) per publish); every row is relabelled
+           only when a gap runs out of midpoints or the mode changes (INTEGRATION.md Limits).
 """
 from __future__ import annotations
 
@@ -820,6 +821,13 @@ class ContextGraph:
             return []
         ids, _, _ = index.recent(since, want)
         return [self._hash_of[i] for i in ids.tolist()]
+
+    def recent_claims(self, since_ms, limit: Optional[int] = 100) -> List[Dict[str, Any]]:
+        """The list ``BatteryNode.get_recent_claims`` returns (lb/node.py:750-762): ``recent`` picks and orders the claims
+        on the GPU, only the chosen ones are turned into the reference's dict literal (:753-760) here."""
+        claims = self.claims
+        return [{"claim_hash": h, "text": claims[h].text, "tags": list(claims[h].tags), "created_ms": claims[h].created_ms,
+                 "parent_hash": claims[h].parent_hash} for h in self.recent(since_ms, limit)]
 
     @_locked
     def compile_many(self, queries: Sequence[str], *, top_k: int = 8, since_ms: Optional[int] = None,

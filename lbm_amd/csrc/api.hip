@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <ctime>
 #include <dlfcn.h>
 #include <exception>
 #include <condition_variable>
@@ -62,6 +63,9 @@ struct lbh_ctx {
     int bq_mode = 2;     // batched scan: 0 = exact fp32 MFMA, 1 = split-bf16 products (3 MFMAs at 16x the fp32 rate),
                          // 2 = one fp16 product (a third of the matrix work, margin 2.2e-3)
     int spin_us = 5000;  // poll the completion ticket this long before blocking in hipStreamSynchronize (0 = always block)
+    int coll_timeout_ms = 60000;  // claim-sharded searches: longest wait for the all-gather (a peer that never arrives) before the call fails
+    int inject_fault = 0;  // TEST HOOK (option "inject_fault", one-shot): 1 = this rank's local search of the next sharded call fails;
+                           // 2 = the next sharded call's stream is held up for 4 x coll_timeout_ms by a sleeping host function
     void* noalloc_scratch = nullptr;  // THIS device's address of search.hip's file-scope scratch array (lbh_search_dev_noalloc)
     std::mutex noalloc_mu;            // calls that share the array on one GPU would race: serialised per context
     std::mutex mu;  // serialises use of the scratch below
@@ -439,6 +443,35 @@ hipError_t wait_ticket(lbh_ctx* c, hipStream_t stream, const int32_t* ticket, in
     return hipStreamSynchronize(stream);
 }
 
+// The same for a call whose stream carries a collective: a peer rank that never arrives (it died, or it failed before
+// its all-gather) must not hang this one, so the wait is bounded -- poll the ticket (NULL: the stream alone), then the
+// stream, for at most coll_timeout_ms.  A timeout leaves the collective queued: the caller marks its communicator broken.
+int wait_collective(lbh_ctx* c, hipStream_t stream, const int32_t* ticket, int32_t seq) {
+    const auto t0 = std::chrono::steady_clock::now();
+    auto elapsed_us = [&] { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); };
+    if (ticket && c->spin_us > 0) {
+        for (int it = 0;; ++it) {
+            if (__atomic_load_n(ticket, __ATOMIC_ACQUIRE) == seq) return LBH_OK;
+            __builtin_ia32_pause();
+            if ((it & 255) == 255 && elapsed_us() > c->spin_us) break;
+        }
+    }
+    for (;;) {
+        if (ticket && __atomic_load_n(ticket, __ATOMIC_ACQUIRE) == seq) return LBH_OK;
+        const hipError_t e = hipStreamQuery(stream);
+        if (e == hipSuccess) {
+            if (!ticket || __atomic_load_n(ticket, __ATOMIC_ACQUIRE) == seq) return LBH_OK;
+            return fail(LBH_E_INTERNAL, "the stream drained without publishing the completion ticket");
+        }
+        if (e != hipErrorNotReady) return fail(LBH_E_DEVICE, "hipStreamQuery: %s", hipGetErrorString(e));
+        if (elapsed_us() > (int64_t)c->coll_timeout_ms * 1000)
+            return fail(LBH_E_DEVICE, "claim-sharded search: no completion after %d ms -- a peer rank never reached the all-gather "
+                                      "(or the device hangs); this communicator is unusable from here on", c->coll_timeout_ms);
+        struct timespec ts = {0, 50000};
+        nanosleep(&ts, nullptr);
+    }
+}
+
 // fp16 copy (tiled, lbh_emb16_off) for the fp16 scans: allocate with the index capacity rounded up to whole 32-row
 // tiles, zero-filled (the pad rows of the last tile are read and masked, never trusted), convert the rows that are
 // not in it yet
@@ -627,6 +660,37 @@ int load_query(lbh_slot* sl, const double* q) {
     return LBH_OK;
 }
 
+// merge step of the claim-sharded search over lists that need not be contiguous: bases[l] = (k + 1) x 6 int64 (lbhip.h, lbh_merge_topk)
+int merge_lists(const int64_t* const* bases, int64_t n_lists, int64_t k, int64_t* out_entries, int64_t* out_count) {
+    struct Ref { double s; const int64_t* e; };
+    std::vector<Ref> all;
+    all.reserve((size_t)(n_lists * k));
+    for (int64_t l = 0; l < n_lists; ++l) {
+        const int64_t* base = bases[l];
+        const int64_t cnt = base[0];
+        if (cnt < 0 || cnt > k) return fail(LBH_E_INVALID, "list %lld announces %lld entries, k = %lld", (long long)l, (long long)cnt, (long long)k);
+        for (int64_t i = 1; i <= cnt; ++i) {
+            double sc;
+            memcpy(&sc, base + i * 6, 8);
+            all.push_back({sc, base + i * 6});
+        }
+    }
+    // lb/context_graph.py:120: score descending (-0.0 == 0.0, as in Python), then hash ascending
+    auto before = [](const Ref& a, const Ref& b) {
+        if (a.s != b.s) return a.s > b.s;
+        for (int w = 2; w < 6; ++w) {
+            const uint64_t x = (uint64_t)a.e[w], y = (uint64_t)b.e[w];
+            if (x != y) return x < y;
+        }
+        return false;
+    };
+    const size_t take = std::min<size_t>((size_t)k, all.size());
+    std::partial_sort(all.begin(), all.begin() + take, all.end(), before);
+    for (size_t i = 0; i < take; ++i) memcpy(out_entries + i * 6, all[i].e, 48);
+    *out_count = (int64_t)take;
+    return LBH_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -665,6 +729,7 @@ int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx) {
     }
     if (const char* e4 = getenv("LBH_BQ_MODE")) c->bq_mode = std::max(0, std::min(2, atoi(e4)));
     if (const char* e3 = getenv("LBH_SPIN_US")) c->spin_us = std::max(0, std::min(1000000, atoi(e3)));
+    if (const char* e7 = getenv("LBH_COLL_TIMEOUT_MS")) c->coll_timeout_ms = std::max(1, std::min(3600000, atoi(e7)));
     hipError_t e0 = hipSetDevice(c->device);
     if (e0 == hipSuccess) e0 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e0 == hipSuccess) e0 = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
@@ -710,6 +775,8 @@ int lbh_set_option(lbh_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "scan_mode")) c->scan_mode = value != 0;
     else if (!strcmp(name, "bq_mode")) c->bq_mode = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else if (!strcmp(name, "spin_us")) c->spin_us = (int)std::max<int64_t>(0, std::min<int64_t>(1000000, value));
+    else if (!strcmp(name, "coll_timeout_ms")) c->coll_timeout_ms = (int)std::max<int64_t>(1, std::min<int64_t>(3600000, value));
+    else if (!strcmp(name, "inject_fault")) c->inject_fault = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else return fail(LBH_E_INVALID, "unknown option %s", name);
     return LBH_OK;
 }
@@ -873,6 +940,18 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
     double batch_norm = 1.0;  // K1 writes unit vectors (or zero)
     std::vector<int64_t> rel;  // must outlive the copies below: freed after the final synchronise
     std::unique_lock<std::mutex> text_lk(c->mu, std::defer_lock);  // the context's text scratch, held until the final synchronise
+    // Every exit below that leaves copies or kernels queued -- a failed enqueue half-way through the slices -- drains both
+    // streams first: the copies read the caller's arrays and `rel`, and the text scratch is released with text_lk.
+    // (Declared after rel and text_lk, so it runs before they go.)  The normal path synchronises once, further down.
+    struct Drain {
+        lbh_ctx* c;
+        bool armed = true;
+        ~Drain() {
+            if (!armed) return;
+            (void)hipStreamSynchronize(c->copy_stream);
+            (void)hipStreamSynchronize(c->stream);
+        }
+    } drain{c};
     if (emb_f64) {
         batch_norm = 0.0;
         for (int64_t i = 0; i < n; ++i) batch_norm = std::max(batch_norm, vec_norm(emb_f64 + i * 64));
@@ -941,6 +1020,7 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
     // ONE synchronisation per call, after the host-side id maps were brought up to date under the GPU's work: the
     // caller's buffers (and `rel`) are free again when this returns
     const hipError_t e_sync = hipStreamSynchronize(s);
+    drain.armed = false;  // `s` waited on every copy-stream event: both streams are idle
     if (e_sync != hipSuccess) {  // the rows are not usable: take them back
         ix->n -= n;
         ix->row_of_id.resize((size_t)id0);
@@ -1184,33 +1264,9 @@ int lbh_index_recent(lbh_index* ix, int64_t since_ms, int64_t limit, uint64_t* o
 int lbh_merge_topk(const int64_t* lists, int64_t n_lists, int64_t k, int64_t* out_entries, int64_t* out_count) try {
     if (n_lists < 0 || k < 0 || (n_lists > 0 && !lists) || !out_count || (k > 0 && !out_entries))
         return fail(LBH_E_INVALID, "bad argument");
-    struct Ref { double s; const int64_t* e; };
-    std::vector<Ref> all;
-    all.reserve((size_t)(n_lists * k));
-    for (int64_t l = 0; l < n_lists; ++l) {
-        const int64_t* base = lists + l * (k + 1) * 6;
-        const int64_t cnt = base[0];
-        if (cnt < 0 || cnt > k) return fail(LBH_E_INVALID, "list %lld announces %lld entries, k = %lld", (long long)l, (long long)cnt, (long long)k);
-        for (int64_t i = 1; i <= cnt; ++i) {
-            double sc;
-            memcpy(&sc, base + i * 6, 8);
-            all.push_back({sc, base + i * 6});
-        }
-    }
-    // lb/context_graph.py:120: score descending (-0.0 == 0.0, as in Python), then hash ascending
-    auto before = [](const Ref& a, const Ref& b) {
-        if (a.s != b.s) return a.s > b.s;
-        for (int w = 2; w < 6; ++w) {
-            const uint64_t x = (uint64_t)a.e[w], y = (uint64_t)b.e[w];
-            if (x != y) return x < y;
-        }
-        return false;
-    };
-    const size_t take = std::min<size_t>((size_t)k, all.size());
-    std::partial_sort(all.begin(), all.begin() + take, all.end(), before);
-    for (size_t i = 0; i < take; ++i) memcpy(out_entries + i * 6, all[i].e, 48);
-    *out_count = (int64_t)take;
-    return LBH_OK;
+    std::vector<const int64_t*> bases((size_t)n_lists);
+    for (int64_t l = 0; l < n_lists; ++l) bases[(size_t)l] = lists + l * (k + 1) * 6;
+    return merge_lists(bases.data(), n_lists, k, out_entries, out_count);
 } LBH_CATCH_ALLOC
 
 int lbh_index_size(lbh_index* ix, int64_t* out_live) {
@@ -1231,12 +1287,13 @@ int lbh_index_get_embedding(lbh_index* ix, uint64_t id, double* out64) {
     return LBH_OK;
 }
 
-int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, int64_t since_ms, uint64_t tag_mask,
-                     uint64_t* out_ids, double* out_scores, int64_t* out_counts, lbh_stats* stats) try {
-    if (!ix || nq < 0 || (nq > 0 && (!q_f64 || !out_counts))) return fail(LBH_E_INVALID, "bad argument");
-    if (k < 0) k = 0;
-    if (k > 0 && nq > 0 && (!out_ids || !out_scores)) return fail(LBH_E_INVALID, "output arrays are NULL");
-    return with_lease(ix, [&](lbh_slot* sl) -> int {
+}  // extern "C"
+
+namespace {
+// nq queries against one index under a lease (the body of lbh_index_search; lbh_index_search_sharded_many runs it as its
+// local part and also wants the hash keys: out_keys = nq x k x 32 bytes, or NULL)
+int search_many(lbh_index* ix, lbh_slot* sl, const double* q_f64, int64_t nq, int64_t k, int64_t since_ms, uint64_t tag_mask,
+                uint64_t* out_ids, double* out_scores, uint8_t* out_keys, int64_t* out_counts, lbh_stats* stats) {
     HIP_TRY(hipSetDevice(ix->ctx->device));
     lbh_stats total;
     memset(&total, 0, sizeof total);
@@ -1295,6 +1352,8 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
                 for (int j = 0; j < r->count; ++j) {
                     out_ids[q * k + j] = ix->id_of_row[r->rows[j]];
                     out_scores[q * k + j] = r->scores[j];
+                    if (out_keys)
+                        for (int w = 0; w < 4; ++w) store_be64(out_keys + (q * k + j) * 32 + 8 * w, r->keys[j][w]);
                 }
                 out_counts[q] = r->count;
                 total.candidates += r->candidates;
@@ -1312,8 +1371,8 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
         lbh_stats st;
         memset(&st, 0, sizeof st);
         st.want_timing = stats ? stats->want_timing : 0;
-        rc = search_loaded(ix, sl, k, since_ms, tag_mask, out_ids + q * k, out_scores + q * k, nullptr, out_counts + q,
-                           stats ? &st : nullptr);
+        rc = search_loaded(ix, sl, k, since_ms, tag_mask, out_ids + q * k, out_scores + q * k, out_keys ? out_keys + q * k * 32 : nullptr,
+                           out_counts + q, stats ? &st : nullptr);
         if (rc) return rc;
         if (stats) {
             if (total.path != 2) {
@@ -1336,6 +1395,18 @@ int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, 
         *stats = total;
     }
     return LBH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int lbh_index_search(lbh_index* ix, const double* q_f64, int64_t nq, int64_t k, int64_t since_ms, uint64_t tag_mask,
+                     uint64_t* out_ids, double* out_scores, int64_t* out_counts, lbh_stats* stats) try {
+    if (!ix || nq < 0 || (nq > 0 && (!q_f64 || !out_counts))) return fail(LBH_E_INVALID, "bad argument");
+    if (k < 0) k = 0;
+    if (k > 0 && nq > 0 && (!out_ids || !out_scores)) return fail(LBH_E_INVALID, "output arrays are NULL");
+    return with_lease(ix, [&](lbh_slot* sl) -> int {
+        return search_many(ix, sl, q_f64, nq, k, since_ms, tag_mask, out_ids, out_scores, nullptr, out_counts, stats);
     });
 } LBH_CATCH_ALLOC
 
@@ -1431,6 +1502,7 @@ struct RcclApi {
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, RcclId128, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommAbort)(void*) = nullptr;  // optional: tears a communicator down without waiting for its queued collectives
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
@@ -1449,6 +1521,7 @@ int rccl_api() {
         g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(g_rccl.lib, "ncclGetUniqueId"));
         g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(g_rccl.lib, "ncclCommInitRank"));
         g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(g_rccl.lib, "ncclCommDestroy"));
+        g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(g_rccl.lib, "ncclCommAbort"));
         g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(g_rccl.lib, "ncclAllGather"));
         g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(g_rccl.lib, "ncclGetErrorString"));
         if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetErrorString)
@@ -1470,18 +1543,74 @@ struct lbh_comm {
     void* comm = nullptr;
     int rank = 0, world = 1;
     std::mutex mu;
+    bool broken = false;               // a collective timed out (a peer never arrived): nothing more can be issued on this communicator
     int64_t* send_dev = nullptr;       // LBH_XCHG_WORDS: this rank's packed list, written by the select kernel
     int64_t* recv_dev = nullptr;       // world x LBH_XCHG_WORDS
     int64_t* recv_host = nullptr;      // the same, device-mapped pinned host memory, + one ticket word behind it
     int64_t* recv_host_dev = nullptr;
     int32_t seq = 0;
-    // top_k > LBH_MAX_PAGE: lists of (k + 1) x 6 words staged through the host (rare)
+    // staged exchange (top_k > LBH_MAX_PAGE, batched queries, lbh_comm_allgather): lists cross through pinned host buffers
     int64_t* big_send_host = nullptr;  // pinned
     int64_t* big_recv_host = nullptr;  // pinned
     int64_t* big_send_dev = nullptr;
     int64_t* big_recv_dev = nullptr;
-    int64_t big_k = 0;
+    int64_t big_bytes = 0;             // capacity of big_send_* (big_recv_*: world times as much)
 };
+
+namespace {
+
+// one rank's failed local search travels as a NEGATIVE count word of its (first) list: every rank takes part in the
+// all-gather, every rank sees the code, every rank returns an error -- nobody is left waiting inside the collective
+int report_peer_failure(const lbh_comm* cm, int r, int64_t code, const std::string& own_error) {
+    if (r == cm->rank && !own_error.empty()) {
+        g_err = own_error;
+        return (int)code;
+    }
+    if (code == LBH_E_INTERNAL)
+        return fail(LBH_E_INTERNAL, "rank %d: its local search failed (e.g. more than %d claims tie on score AND carry the same 32-byte hash key)", r, LBH_MCAP);
+    return fail(LBH_E_DEVICE, "rank %d: its local search failed with code %lld; every rank fails this query together", r, (long long)code);
+}
+
+int ensure_staged(lbh_comm* cm, int64_t bytes) {
+    if (bytes <= cm->big_bytes) return LBH_OK;
+    void* dev[] = {cm->big_send_dev, cm->big_recv_dev};
+    for (void* p : dev)
+        if (p) (void)hipFree(p);
+    void* host[] = {cm->big_send_host, cm->big_recv_host};
+    for (void* p : host)
+        if (p) (void)hipHostFree(p);
+    cm->big_send_dev = cm->big_recv_dev = cm->big_send_host = cm->big_recv_host = nullptr;
+    cm->big_bytes = 0;
+    const size_t cap = (size_t)std::max<int64_t>(bytes, 1 << 16), W = (size_t)cm->world;
+    HIP_TRY(hipMalloc((void**)&cm->big_send_dev, cap));
+    HIP_TRY(hipMalloc((void**)&cm->big_recv_dev, cap * W));
+    HIP_TRY(hipHostMalloc((void**)&cm->big_send_host, cap, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&cm->big_recv_host, cap * W, hipHostMallocDefault));
+    cm->big_bytes = (int64_t)cap;
+    return LBH_OK;
+}
+
+void sleepy_host_fn(void* ms) {  // test hook "inject_fault" = 2: holds the stream up like a peer that is late
+    struct timespec ts = {(time_t)((intptr_t)ms / 1000), (long)((intptr_t)ms % 1000) * 1000000L};
+    nanosleep(&ts, nullptr);
+}
+
+// big_send_host (bytes, already filled) -> all ranks' copies in big_recv_host, through device buffers; bounded wait
+int staged_allgather(lbh_comm* cm, hipStream_t s, size_t bytes) {
+    lbh_ctx* c = cm->ctx;
+    if (c->inject_fault == 2) {
+        c->inject_fault = 0;
+        HIP_TRY(hipLaunchHostFunc(s, sleepy_host_fn, (void*)(intptr_t)(4 * (int64_t)c->coll_timeout_ms)));
+    }
+    HIP_TRY(hipMemcpyAsync(cm->big_send_dev, cm->big_send_host, bytes, hipMemcpyHostToDevice, s));
+    RCCL_TRY(g_rccl.AllGather(cm->big_send_dev, cm->big_recv_dev, bytes, NCCL_INT8, cm->comm, s));
+    HIP_TRY(hipMemcpyAsync(cm->big_recv_host, cm->big_recv_dev, bytes * (size_t)cm->world, hipMemcpyDeviceToHost, s));
+    const int rc = wait_collective(c, s, nullptr, 0);
+    if (rc) cm->broken = true;
+    return rc;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -1496,6 +1625,13 @@ int lbh_comm_unique_id(uint8_t* out_id) {
 int lbh_comm_destroy(lbh_comm* cm) {
     if (!cm) return LBH_OK;
     (void)hipSetDevice(cm->ctx->device);
+    if (cm->broken) {
+        // a collective is still queued behind a peer that never came: neither the stream nor ncclCommDestroy would return.
+        // Abort the communicator where RCCL offers it and leave the buffers to the process's exit.
+        if (cm->comm && g_rccl.CommAbort) (void)g_rccl.CommAbort(cm->comm);
+        delete cm;
+        return LBH_OK;
+    }
     (void)hipStreamSynchronize(cm->ctx->stream);
     if (cm->comm) (void)g_rccl.CommDestroy(cm->comm);
     void* dev[] = {cm->send_dev, cm->recv_dev, cm->big_send_dev, cm->big_recv_dev};
@@ -1525,12 +1661,9 @@ int lbh_comm_init(lbh_ctx* c, const uint8_t* id, int rank, int world, lbh_comm**
         g_err = why;
         return code;
     };
-    RcclId128 uid;
-    memcpy(uid.b, id, sizeof uid.b);
-    {
-        const int r = g_rccl.CommInitRank(&cm->comm, world, uid, rank);
-        if (r != 0) return bail(fail(LBH_E_DEVICE, "ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString(r)));
-    }
+    // everything that can fail on ONE rank alone comes before the collective call, so that a rank which cannot take part
+    // fails here, before its peers are inside ncclCommInitRank waiting for it (callers agree on these results first:
+    // bench.py)
     const size_t words = (size_t)LBH_XCHG_WORDS;
     hipError_t e = hipMalloc((void**)&cm->send_dev, words * 8);
     if (e == hipSuccess) e = hipMalloc((void**)&cm->recv_dev, words * 8 * (size_t)world);
@@ -1539,7 +1672,33 @@ int lbh_comm_init(lbh_ctx* c, const uint8_t* id, int rank, int world, lbh_comm**
     if (e == hipSuccess) e = hipMemset(cm->send_dev, 0, words * 8);
     if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? LBH_E_NOMEM : LBH_E_DEVICE, "exchange buffers: %s", hipGetErrorString(e)));
     memset(cm->recv_host, 0, words * 8 * (size_t)world + 64);
+    RcclId128 uid;
+    memcpy(uid.b, id, sizeof uid.b);
+    {
+        const int r = g_rccl.CommInitRank(&cm->comm, world, uid, rank);
+        if (r != 0) {
+            cm->comm = nullptr;
+            return bail(fail(LBH_E_DEVICE, "ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString(r)));
+        }
+    }
     *out_comm = cm;
+    return LBH_OK;
+}
+
+int lbh_comm_allgather(lbh_comm* cm, const void* send, int64_t bytes, void* recv) {
+    if (!cm || bytes < 0 || (bytes > 0 && (!send || !recv))) return fail(LBH_E_INVALID, "bad argument");
+    if (bytes == 0) return LBH_OK;
+    if (bytes > ((int64_t)1 << 30)) return fail(LBH_E_INVALID, "lbh_comm_allgather moves at most 1 GiB per rank");
+    std::lock_guard<std::mutex> lk(cm->mu);
+    if (cm->broken) return fail(LBH_E_DEVICE, "this communicator is unusable: an earlier collective timed out");
+    lbh_ctx* c = cm->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_staged(cm, bytes);
+    if (rc) return rc;
+    memcpy(cm->big_send_host, send, (size_t)bytes);
+    rc = staged_allgather(cm, c->stream, (size_t)bytes);
+    if (rc) return rc;
+    memcpy(recv, cm->big_recv_host, (size_t)bytes * (size_t)cm->world);
     return LBH_OK;
 }
 
@@ -1554,10 +1713,13 @@ int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, i
     // collectives of one communicator are issued in the same order on every rank: one sharded search at a time per
     // communicator (taken before the index lease; mutators never take it)
     std::lock_guard<std::mutex> lk2(cm->mu);
+    if (cm->broken) return fail(LBH_E_DEVICE, "this communicator is unusable: an earlier collective timed out");
     return with_lease(ix, [&](lbh_slot* sl) -> int {
     lbh_ctx* c = ix->ctx;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = sl->stream;
+    // Argument errors (a non-finite query) are the same on every rank -- the call is collective, same arguments
+    // everywhere -- so returning here leaves nobody behind.
     int rc = load_query(sl, q_f64);
     if (rc) return rc;
     if (stats) {
@@ -1569,7 +1731,7 @@ int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, i
     const bool timing = stats && stats->want_timing;
     const int W = cm->world;
     std::vector<int64_t> merged;
-    int64_t kk = k;  // entries per list
+    std::string own_error;  // what went wrong in THIS rank's local part (the exchange still runs)
     const int64_t* lists = nullptr;
     if (k <= LBH_MAX_PAGE) {
         // Stream-ordered, one host wait: fp32 scan -> select (writes the packed list to cm->send_dev) -> exact fp64 scan
@@ -1581,11 +1743,18 @@ int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, i
         const lbh_xchg xc{cm->send_dev, gid_mul, gid_add};
         const float nscale = norm_scale(ix, sl->qnorm);
         const int32_t seq = sl->seq = (sl->seq == INT32_MAX) ? 1 : sl->seq + 1;
-        HIP_TRY(hipMemsetAsync(cm->send_dev, 0, 48, s));  // count 0 if this shard is empty / nothing passes
-        if (ix->n > 0) {
+        const bool half = ix->n > 0 && c->scan_mode == 1 && nscale <= 1.001f && nscale >= 0.25f;
+        if (half && !emb16_current(ix)) return LBH_NEED_EMB16;  // nothing queued yet: rebuilt under the exclusive lock, then retried
+        // From the first enqueue on, no rank may leave before the all-gather: a local failure is recorded, the list's
+        // count word carries its (negative) code, and the exchange runs regardless.
+        auto local = [&]() -> int {
+            if (c->inject_fault == 1) {
+                c->inject_fault = 0;
+                return fail(LBH_E_DEVICE, "injected fault (test hook): the local search of this rank fails");
+            }
+            HIP_TRY(hipMemsetAsync(cm->send_dev, 0, 48, s));  // count 0 if this shard is empty / nothing passes
+            if (ix->n == 0) return LBH_OK;
             const int grid = lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu);
-            const bool half = c->scan_mode == 1 && nscale <= 1.001f && nscale >= 0.25f;
-            if (half && !emb16_current(ix)) return LBH_NEED_EMB16;
             HIP_TRY(lbh_launch_search_fast(dv, half ? ix->emb16 : nullptr, sl->ws, nullptr, sl->qarg, page, has_since, since_ms, tag_mask,
                                            (half && !has_since && !tag_mask) ? lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu, true) : grid,
                                            c->n_cu, c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, timing ? sl->ev[0] : nullptr,
@@ -1599,13 +1768,47 @@ int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, i
                 stats->bytes_per_row = (half ? 128 : 256) + (has_since ? 8 : 0) + (tag_mask ? 8 : 0);
                 stats->scan_launches = 1;
             }
+            return LBH_OK;
+        };
+        const int lrc = local();
+        if (lrc) {
+            own_error = g_err;
+            static const int64_t code_words[4] = {LBH_E_DEVICE, 0, 0, 0};  // any local failure travels as LBH_E_DEVICE
+            // pageable source: the runtime stages these 8 bytes before the call returns
+            if (hipMemcpyAsync(cm->send_dev, code_words, 8, hipMemcpyHostToDevice, s) != hipSuccess) {
+                cm->broken = true;  // this rank cannot even announce its failure: its peers run into their timeout
+                g_err = own_error;
+                return lrc;
+            }
         }
-        RCCL_TRY(g_rccl.AllGather(cm->send_dev, cm->recv_dev, (size_t)LBH_XCHG_WORDS * 8, NCCL_INT8, cm->comm, s));
+        if (c->inject_fault == 2) {
+            c->inject_fault = 0;
+            HIP_TRY(hipLaunchHostFunc(s, sleepy_host_fn, (void*)(intptr_t)(4 * (int64_t)c->coll_timeout_ms)));
+        }
+        {
+            const int r = g_rccl.AllGather(cm->send_dev, cm->recv_dev, (size_t)LBH_XCHG_WORDS * 8, NCCL_INT8, cm->comm, s);
+            if (r != 0) {
+                cm->broken = true;
+                return fail(LBH_E_DEVICE, "ncclAllGather: %s", g_rccl.GetErrorString(r));
+            }
+        }
         const int32_t xseq = cm->seq = (cm->seq == INT32_MAX) ? 1 : cm->seq + 1;
         int32_t* ticket_host = reinterpret_cast<int32_t*>(cm->recv_host + (size_t)LBH_XCHG_WORDS * W);
         int32_t* ticket_dev = reinterpret_cast<int32_t*>(cm->recv_host_dev + (size_t)LBH_XCHG_WORDS * W);
-        HIP_TRY(lbh_launch_xchg_publish(cm->recv_dev, cm->recv_host_dev, LBH_XCHG_WORDS * W, ticket_dev, xseq, s));
-        HIP_TRY(wait_ticket(c, s, ticket_host, xseq));
+        hipError_t pe = lbh_launch_xchg_publish(cm->recv_dev, cm->recv_host_dev, LBH_XCHG_WORDS * W, ticket_dev, xseq, s);
+        if (pe != hipSuccess) {
+            cm->broken = true;
+            return fail(LBH_E_DEVICE, "xchg_publish_kernel: %s", hipGetErrorString(pe));
+        }
+        rc = wait_collective(c, s, ticket_host, xseq);
+        if (rc) {
+            cm->broken = true;
+            return rc;
+        }
+        for (int r = 0; r < W; ++r) {
+            const int64_t head = cm->recv_host[(size_t)r * LBH_XCHG_WORDS];
+            if (head < 0) return report_peer_failure(cm, r, head == -1 ? LBH_E_INTERNAL : head, own_error);  // -1: the select kernels' duplicate-key report
+        }
         if (timing && ix->n > 0) {
             HIP_TRY(hipEventSynchronize(sl->ev[1]));
             float ms = 0.f;
@@ -1615,60 +1818,57 @@ int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, i
             const lbh_result* r = sl->ws.result_host;
             stats->candidates = r->candidates;
         }
-        // lists are LBH_MAX_PAGE + 1 rows apart; lbh_merge_topk wants (kk + 1) rows: compact in place on the host copy
+        // lists are LBH_MAX_PAGE + 1 rows apart; the merge wants (k + 1) rows: compact on the host copy
         merged.resize((size_t)W * (size_t)(k + 1) * 6);
-        for (int r = 0; r < W; ++r) {
-            const int64_t* src = cm->recv_host + (size_t)r * LBH_XCHG_WORDS;
-            if (src[0] < 0) return fail(LBH_E_INTERNAL, "rank %d: more than %d claims tie on score AND carry the same 32-byte hash key", r, LBH_MCAP);
-            memcpy(merged.data() + (size_t)r * (size_t)(k + 1) * 6, src, (size_t)(k + 1) * 48);
-        }
+        for (int r = 0; r < W; ++r)
+            memcpy(merged.data() + (size_t)r * (size_t)(k + 1) * 6, cm->recv_host + (size_t)r * LBH_XCHG_WORDS, (size_t)(k + 1) * 48);
         lists = merged.data();
     } else {
         // top_k beyond one device page: the local pages are collected on the host (fast page + exact pages), then exchanged
         // through staging buffers.  Rare, and dominated by the paged scans anyway.
-        const int64_t kl = std::min<int64_t>(k, std::max<int64_t>(ix->n, 1));
-        (void)kl;
-        if (cm->big_k < k) {
-            void* dev[] = {cm->big_send_dev, cm->big_recv_dev};
-            for (void* p : dev)
-                if (p) (void)hipFree(p);
-            void* host[] = {cm->big_send_host, cm->big_recv_host};
-            for (void* p : host)
-                if (p) (void)hipHostFree(p);
-            cm->big_send_dev = cm->big_recv_dev = cm->big_send_host = cm->big_recv_host = nullptr;
-            cm->big_k = 0;
-            const size_t bytes = (size_t)(k + 1) * 48;
-            HIP_TRY(hipMalloc((void**)&cm->big_send_dev, bytes));
-            HIP_TRY(hipMalloc((void**)&cm->big_recv_dev, bytes * (size_t)W));
-            HIP_TRY(hipHostMalloc((void**)&cm->big_send_host, bytes, hipHostMallocDefault));
-            HIP_TRY(hipHostMalloc((void**)&cm->big_recv_host, bytes * (size_t)W, hipHostMallocDefault));
-            cm->big_k = k;
+        if (k > ((int64_t)1 << 24)) return fail(LBH_E_INVALID, "claim-sharded search: top_k beyond 2^24");  // the same on every rank
+        const size_t bytes = (size_t)(k + 1) * 48;
+        rc = ensure_staged(cm, (int64_t)bytes);  // an allocation failure here leaves the peers to their timeout
+        if (rc) {
+            cm->broken = true;
+            return rc;
         }
         std::vector<uint64_t> ids((size_t)k);
         std::vector<double> sc((size_t)k);
         std::vector<uint8_t> keys((size_t)k * 32);
         int64_t got = 0;
-        rc = search_loaded(ix, sl, k, since_ms, tag_mask, ids.data(), sc.data(), keys.data(), &got, stats);
-        if (rc) return rc;
-        int64_t* sh = cm->big_send_host;
-        memset(sh, 0, (size_t)(k + 1) * 48);
-        sh[0] = got;
-        for (int64_t i = 0; i < got; ++i) {
-            int64_t* e = sh + 6 * (i + 1);
-            memcpy(&e[0], &sc[(size_t)i], 8);
-            e[1] = (int64_t)(ids[(size_t)i] * gid_mul + gid_add);
-            for (int w = 0; w < 4; ++w) e[2 + w] = (int64_t)load_be64(keys.data() + i * 32 + 8 * w);
+        int lrc = LBH_OK;
+        if (c->inject_fault == 1) {
+            c->inject_fault = 0;
+            lrc = fail(LBH_E_DEVICE, "injected fault (test hook): the local search of this rank fails");
+        } else {
+            lrc = search_loaded(ix, sl, k, since_ms, tag_mask, ids.data(), sc.data(), keys.data(), &got, stats);
         }
-        const size_t bytes = (size_t)(k + 1) * 48;
-        HIP_TRY(hipMemcpyAsync(cm->big_send_dev, sh, bytes, hipMemcpyHostToDevice, s));
-        RCCL_TRY(g_rccl.AllGather(cm->big_send_dev, cm->big_recv_dev, bytes, NCCL_INT8, cm->comm, s));
-        HIP_TRY(hipMemcpyAsync(cm->big_recv_host, cm->big_recv_dev, bytes * (size_t)W, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        int64_t* sh = cm->big_send_host;
+        memset(sh, 0, bytes);
+        if (lrc) {
+            own_error = g_err;
+            sh[0] = lrc;
+        } else {
+            sh[0] = got;
+            for (int64_t i = 0; i < got; ++i) {
+                int64_t* e = sh + 6 * (i + 1);
+                memcpy(&e[0], &sc[(size_t)i], 8);
+                e[1] = (int64_t)(ids[(size_t)i] * gid_mul + gid_add);
+                for (int w = 0; w < 4; ++w) e[2 + w] = (int64_t)load_be64(keys.data() + i * 32 + 8 * w);
+            }
+        }
+        rc = staged_allgather(cm, s, bytes);
+        if (rc) return rc;
         lists = cm->big_recv_host;
+        for (int r = 0; r < W; ++r) {
+            const int64_t head = lists[(size_t)r * (size_t)(k + 1) * 6];
+            if (head < 0) return report_peer_failure(cm, r, head, own_error);
+        }
     }
-    std::vector<int64_t> top((size_t)std::max<int64_t>(kk, 1) * 6);
+    std::vector<int64_t> top((size_t)std::max<int64_t>(k, 1) * 6);
     int64_t cnt = 0;
-    rc = lbh_merge_topk(lists, W, kk, top.data(), &cnt);
+    rc = lbh_merge_topk(lists, W, k, top.data(), &cnt);
     if (rc) return rc;
     for (int64_t i = 0; i < cnt; ++i) {
         const int64_t* e = top.data() + i * 6;
@@ -1678,6 +1878,95 @@ int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, i
             for (int w = 0; w < 4; ++w) store_be64(out_keys + i * 32 + 8 * w, (uint64_t)e[2 + w]);
     }
     *out_count = cnt;
+    return LBH_OK;
+    });
+} LBH_CATCH_ALLOC
+
+int lbh_index_search_sharded_many(lbh_index* ix, lbh_comm* cm, const double* q_f64, int64_t nq, int64_t k, int64_t since_ms,
+                                  uint64_t tag_mask, uint64_t gid_mul, uint64_t gid_add, uint64_t* out_gids, double* out_scores,
+                                  uint8_t* out_keys, int64_t* out_counts, lbh_stats* stats) try {
+    if (!ix || !cm || nq < 0 || (nq > 0 && (!q_f64 || !out_counts))) return fail(LBH_E_INVALID, "bad argument");
+    if (cm->ctx != ix->ctx) return fail(LBH_E_INVALID, "the communicator and the index belong to different contexts");
+    if (k < 0) k = 0;
+    if (k > 0 && nq > 0 && (!out_gids || !out_scores)) return fail(LBH_E_INVALID, "output arrays are NULL");
+    for (int64_t q = 0; q < nq; ++q) out_counts[q] = 0;
+    if (stats) {
+        const int32_t wt = stats->want_timing;
+        memset(stats, 0, sizeof *stats);
+        stats->want_timing = wt;
+    }
+    if (nq == 0 || k == 0) return LBH_OK;  // on every rank alike: no collective for an empty request
+    const int64_t per = (k + 1) * 6;  // int64 words of one query's list
+    if (nq > ((int64_t)1 << 20) || k > ((int64_t)1 << 24) || nq * per * 8 > ((int64_t)1 << 30))
+        return fail(LBH_E_INVALID, "claim-sharded batch: nq x (top_k + 1) x 48 bytes exceeds 1 GiB per rank");
+    std::lock_guard<std::mutex> lk2(cm->mu);
+    if (cm->broken) return fail(LBH_E_DEVICE, "this communicator is unusable: an earlier collective timed out");
+    return with_lease(ix, [&](lbh_slot* sl) -> int {
+    lbh_ctx* c = ix->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const int W = cm->world;
+    const size_t bytes = (size_t)(nq * per) * 8;
+    // local part: the batched (matrix-core) search of lbh_index_search on this rank's shard, keys included
+    std::vector<uint64_t> ids((size_t)(nq * k));
+    std::vector<double> sc((size_t)(nq * k));
+    std::vector<uint8_t> keys((size_t)(nq * k) * 32);
+    std::vector<int64_t> cnts((size_t)nq, 0);
+    int lrc;
+    if (c->inject_fault == 1) {
+        c->inject_fault = 0;
+        lrc = fail(LBH_E_DEVICE, "injected fault (test hook): the local search of this rank fails");
+    } else {
+        lrc = search_many(ix, sl, q_f64, nq, k, since_ms, tag_mask, ids.data(), sc.data(), keys.data(), cnts.data(), stats);
+    }
+    if (lrc == LBH_NEED_EMB16) return lrc;  // nothing of the exchange has been queued: fp16 copy rebuilt, body retried
+    int rc = ensure_staged(cm, (int64_t)bytes);  // an allocation failure here leaves the peers to their timeout
+    if (rc) {
+        cm->broken = true;
+        return rc;
+    }
+    // A local failure does not excuse this rank from the all-gather: the first list's count word carries the code and
+    // every rank fails the batch together.
+    std::string own_error;
+    int64_t* sh = cm->big_send_host;
+    memset(sh, 0, bytes);
+    if (lrc) {
+        own_error = g_err;
+        sh[0] = lrc;
+    } else {
+        for (int64_t q = 0; q < nq; ++q) {
+            int64_t* base = sh + q * per;
+            base[0] = cnts[(size_t)q];
+            for (int64_t i = 0; i < cnts[(size_t)q]; ++i) {
+                int64_t* e = base + 6 * (i + 1);
+                memcpy(&e[0], &sc[(size_t)(q * k + i)], 8);
+                e[1] = (int64_t)(ids[(size_t)(q * k + i)] * gid_mul + gid_add);
+                for (int w = 0; w < 4; ++w) e[2 + w] = (int64_t)load_be64(keys.data() + (size_t)(q * k + i) * 32 + 8 * w);
+            }
+        }
+    }
+    rc = staged_allgather(cm, sl->stream, bytes);  // ONE all-gather for the whole batch
+    if (rc) return rc;
+    const int64_t* all = cm->big_recv_host;
+    for (int r = 0; r < W; ++r) {
+        const int64_t head = all[(size_t)r * (size_t)(nq * per)];
+        if (head < 0) return report_peer_failure(cm, r, head, own_error);
+    }
+    std::vector<const int64_t*> bases((size_t)W);
+    std::vector<int64_t> top((size_t)k * 6);
+    for (int64_t q = 0; q < nq; ++q) {
+        for (int r = 0; r < W; ++r) bases[(size_t)r] = all + (size_t)r * (size_t)(nq * per) + (size_t)(q * per);
+        int64_t cnt = 0;
+        rc = merge_lists(bases.data(), W, k, top.data(), &cnt);
+        if (rc) return rc;
+        for (int64_t i = 0; i < cnt; ++i) {
+            const int64_t* e = top.data() + i * 6;
+            memcpy(&out_scores[q * k + i], &e[0], 8);
+            out_gids[q * k + i] = (uint64_t)e[1];
+            if (out_keys)
+                for (int w = 0; w < 4; ++w) store_be64(out_keys + (size_t)(q * k + i) * 32 + 8 * w, (uint64_t)e[2 + w]);
+        }
+        out_counts[q] = cnt;
+    }
     return LBH_OK;
     });
 } LBH_CATCH_ALLOC

@@ -60,8 +60,10 @@ def _claim_fields(obj: Dict[str, Any]) -> Dict[str, Any]:
 
 
 def _replay_ops(txs: Iterable[Dict[str, Any]]):
-    """(op, claim_hash, add_claim fields | None) for every transaction that changes a graph, in stream order.  Anything
-    malformed is skipped, as the reference skips a claim it cannot rebuild (it logs and continues, lb/node.py:507-509)."""
+    """(op, claim_hash, stored object | None) for every transaction that changes a graph, in stream order.
+    lb/node.py:493-513: a claim needs a ``str`` hash that the CAS holds -- here: the transaction carries an ``object``
+    key at all -- and ``cas.get_json(h) or {}`` turns every falsy object (None, {}, [], 0, "") into an EMPTY claim;
+    what the object is worth is decided where the claim is added (``rebuild_group_graph``)."""
     for tx in txs:
         kind = tx.get("type")
         if kind == "retract":
@@ -69,14 +71,9 @@ def _replay_ops(txs: Iterable[Dict[str, Any]]):
             if isinstance(target, str):
                 yield "retract", target, None
         elif kind == "claim":
-            claim_hash, obj = tx.get("artifact_hash"), tx.get("object")
-            if not (isinstance(claim_hash, str) and isinstance(obj, dict)):
-                continue
-            try:
-                fields = _claim_fields(obj)
-            except (TypeError, ValueError):
-                continue
-            yield "claim", claim_hash, fields
+            claim_hash = tx.get("artifact_hash")
+            if isinstance(claim_hash, str) and "object" in tx:
+                yield "claim", claim_hash, (tx["object"] or {})
 
 
 class RetrievalNode:
@@ -106,16 +103,20 @@ class RetrievalNode:
     def rebuild_group_graph(self, group_id: str, txs: Iterable[Dict[str, Any]]) -> None:
         """lb/node.py:486-515 without the chain and the CAS (out of scope): ``txs`` is the group's transaction stream
         with the claim objects already resolved -- ``{"type": "claim", "artifact_hash": h, "object": {...}}`` (what
-        ``cas.get_json(h)`` returns; a missing / non-dict object skips the claim like a CAS miss does) and
+        ``cas.get_json(h)`` returns; no ``object`` key = a CAS miss, skipped; a falsy object = an empty claim; anything that
+        raises while it is read -- a truthy non-dict, ``created_ms`` = Infinity, tags that are not iterable -- skips the claim) and
         ``{"type": "retract", "claim_hash": h}``.  A NEW graph replaces the group's, exactly as in the reference; every
         claim it keeps is vectorised in one K1 launch at the first query and the retracts never reach the device."""
         group = self._require_group(group_id)
         fresh = ContextGraph()
-        for op, claim_hash, fields in _replay_ops(txs):
+        for op, claim_hash, obj in _replay_ops(txs):
             if op == "retract":
                 fresh.retract(claim_hash)
-            else:
-                fresh.add_claim(claim_hash, **fields)
+                continue
+            try:  # lb/node.py:497-509: ANY exception while rebuilding one claim skips that claim and nothing else
+                fresh.add_claim(claim_hash, **_claim_fields(obj))
+            except Exception:
+                continue
         group.graph = fresh
 
     def compile_context_many(self, group_id: str, queries: Sequence[str], *, top_k: int = 8,
@@ -130,18 +131,7 @@ class RetrievalNode:
 
     def get_recent_claims(self, group_id: str, since_ms: int, *, limit: int = 100) -> List[Dict[str, Any]]:
         """lb/node.py:736-762: claims created at or after ``since_ms``, newest first, at most ``limit``.
-        The filter + sort + cut run on the GPU (``ContextGraph.recent``); only the chosen claims are
-        turned into dicts here."""
+        The filter + sort + cut run on the GPU (``ContextGraph.recent``); only the chosen claims are turned into
+        dicts (``ContextGraph.recent_claims``; a claim-sharded graph gathers them from their owners)."""
         g = self._require_group(group_id)
-        claims = g.graph.claims
-        out = []
-        for h in g.graph.recent(since_ms, limit):
-            c = claims[h]
-            out.append({
-                "claim_hash": h,
-                "text": c.text,
-                "tags": list(c.tags),
-                "created_ms": c.created_ms,
-                "parent_hash": c.parent_hash,
-            })
-        return out
+        return g.graph.recent_claims(since_ms, limit)

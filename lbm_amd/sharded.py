@@ -16,7 +16,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .context_graph import _HEX64, ContextGraph
+from .context_graph import _HEX64, ContextGraph, LazyContext, format_context
 
 ENTRY_WORDS = 6  # score bits, global id, 4 key words  (48 bytes)
 
@@ -81,6 +81,10 @@ class _Buffers:
         self.on_gpu = on_gpu
 
 
+class ShardPeerError(RuntimeError):
+    """Another rank's local search failed; every rank fails that query together instead of waiting for it."""
+
+
 class ShardedSearcher:
     """Wraps a rank-local search function with the all-gather merge.
 
@@ -91,6 +95,10 @@ class ShardedSearcher:
     Per query: pack k entries into pinned memory, one async H2D copy, ONE ``all_gather_into_tensor``
     (RCCL over xGMI under backend "nccl"), one async D2H copy into pinned memory, one stream
     synchronisation, then the host merge of the k*N entries.
+
+    A rank whose local search raises still takes part in the all-gather -- its list's count word is -1 -- and then
+    every rank raises: the failing one its own exception, the others ``ShardPeerError``.  Nobody waits for a list
+    that will never come.
     """
 
     def __init__(self, local_search: Callable, rank: int, world: int, *, device=None, group=None,
@@ -103,17 +111,33 @@ class ShardedSearcher:
         self._merge = merge_entries if c_merge else merge_gathered
         self._bufs = {}
 
-    def search(self, q: np.ndarray, k: int, since_ms: int, tag_mask: int = 0):
-        k = max(0, int(k))
-        ids, scores, keys = self.local_search(q, k, since_ms, tag_mask)
-        local = pack_local(scores, self.gid_of_local(np.asarray(ids)), keys, k)
+    def _local_lists(self, qs: np.ndarray, k: int, since_ms: int, tag_mask: int, failed: Optional[BaseException]):
+        """-> (int64 [nq, k + 1, 6], exception or None).  ``failed``: the caller's own local phase already failed."""
+        out = np.zeros((len(qs), k + 1, ENTRY_WORDS), dtype=np.int64)
+        try:
+            if failed is not None:
+                raise failed
+            for j, q in enumerate(qs):
+                ids, scores, keys = self.local_search(q, k, since_ms, tag_mask)
+                out[j] = pack_local(scores, self.gid_of_local(np.asarray(ids)), keys, k)
+        except Exception as e:  # noqa: BLE001 -- whatever it is, the peers must hear of it through the exchange
+            out[...] = 0
+            out[0, 0, 0] = -1
+            return out, e
+        return out, None
+
+    def _gather(self, local: np.ndarray) -> np.ndarray:
+        """local: int64 [rows, 6] -> [world, rows, 6] (rank-major), one all-gather."""
+        rows = local.shape[0]
         if self.world == 1 and not self.always_gather:
-            return self._merge(local[None], k)
+            return local[None]
         import torch
         import torch.distributed as dist
-        b = self._bufs.get(k)
+        b = self._bufs.get(rows)
         if b is None:
-            b = self._bufs[k] = _Buffers(k, self.world, self.device)
+            if len(self._bufs) > 32:
+                self._bufs.clear()
+            b = self._bufs[rows] = _Buffers(rows - 1, self.world, self.device)
         b.send_np[...] = local
         if b.on_gpu:
             b.send_dev.copy_(b.send_host, non_blocking=True)
@@ -121,7 +145,25 @@ class ShardedSearcher:
         if b.on_gpu:
             b.recv_host.copy_(b.recv_dev, non_blocking=True)
             torch.cuda.current_stream(b.recv_dev.device).synchronize()
-        return self._merge(b.recv_np, k)
+        return b.recv_np
+
+    def search_many(self, qs, k: int, since_ms: int, tag_mask: int = 0, failed: Optional[BaseException] = None):
+        """Batch of queries, ONE all-gather of all their lists -> [(global ids, scores, key words)] per query."""
+        k = max(0, int(k))
+        qs = list(qs)
+        if not qs:
+            return []
+        local, err = self._local_lists(qs, k, since_ms, tag_mask, failed)
+        g = self._gather(local.reshape(len(qs) * (k + 1), ENTRY_WORDS)).reshape(self.world, len(qs), k + 1, ENTRY_WORDS)
+        bad = [r for r in range(self.world) if g[r, 0, 0, 0] < 0]
+        if err is not None:
+            raise err
+        if bad:
+            raise ShardPeerError(f"claim-sharded search: the local search of rank(s) {bad} failed; this query fails on every rank")
+        return [self._merge(np.ascontiguousarray(g[:, j]), k) for j in range(len(qs))]
+
+    def search(self, q: np.ndarray, k: int, since_ms: int, tag_mask: int = 0, failed: Optional[BaseException] = None):
+        return self.search_many([q], k, since_ms, tag_mask, failed)[0]
 
 
 def owner_of(claim_hash: str, world: int) -> int:
@@ -131,17 +173,26 @@ def owner_of(claim_hash: str, world: int) -> int:
 
 
 class ShardedContextGraph(ContextGraph):
-    """``ContextGraph`` over the GPUs of a node, one process per GPU (SPMD): every rank applies the SAME sequence of
-    ``add_claim`` / ``retract`` / dict edits -- the way every node of the reference replays the same chain -- and keeps the
-    host-side ``claims`` dict in full, but only the claims it owns (``owner_of(hash)``) get a row in its GPU's index.
+    """``ContextGraph`` over the GPUs of a node, one process per GPU (SPMD): every rank is handed the SAME sequence of
+    ``add_claim`` / ``retract`` calls -- the way every node of the reference replays the same chain -- but KEEPS only the
+    claims it owns (``owner_of(hash)``): their ``Claim`` objects in ``claims`` (this rank's shard of the reference's dict,
+    lb/context_graph.py:57) and their rows in its GPU's index.  Host and device state per rank are ~ N / world, so a
+    100 M-claim corpus on 8 ranks holds 12.5 M ``Claim`` objects per process, not 100 M.  What every rank does track for
+    every claim it is shown is O(1): the tag -> bit table (so that the ranks' tag masks mean the same), the kind of hash
+    (hex / short free-form) and a global operation counter (the ``claims``-dict position stamp of the recency query).
+
     ``compile`` is collective: each rank ranks its shard (same kernels as the single-GPU graph), the ranks exchange their
     top-k lists once -- ``lbh_index_search_sharded`` (RCCL all-gather over xGMI inside liblbhip) when a ``comm`` is given,
-    else ``torch.distributed`` on ``group`` (gloo in the CPU tests) -- and merge them with the reference's comparator, so
-    every rank returns exactly what one ``ContextGraph`` holding all claims returns (lb/context_graph.py:91-133).
+    else ``torch.distributed`` on ``group`` (gloo in the CPU tests) -- and merge them with the reference's comparator; the
+    owners of the k winners then hand their (text, tags) to every rank in a second small exchange, and every rank formats
+    and returns exactly what one ``ContextGraph`` holding all claims returns (lb/context_graph.py:91-133).
+    ``compile_many`` does the same for a batch (local K3 pass, one exchange of all lists); ``recent`` / ``recent_claims``
+    merge the ranks' newest-first lists (lb/node.py:736-762); ``snapshot`` gathers the shards into the reference's form.
 
     Claim hashes must order like their 32-byte keys on every rank: either all 64-hex CAS hashes or all short strings
-    (<= 32 UTF-8 bytes, no NUL).  Anything else raises ``ValueError`` at the next query (rank keys are private to one
-    index and cannot be merged across shards)."""
+    (<= 32 UTF-8 bytes, no NUL).  Anything else raises ``ValueError`` at the next query, on every rank alike (rank keys
+    are private to one index and cannot be merged across shards).  Edits made by hand to ``claims`` or to a ``Claim``
+    reach only the rank they are made on: SPMD callers go through ``add_claim`` / ``retract``."""
 
     _overlap_searches = False  # a search here is a collective: every rank must issue them in the same order, one at a time
 
@@ -153,6 +204,8 @@ class ShardedContextGraph(ContextGraph):
         self._comm, self._group = comm, group
         self._index_factory, self._embed_fn = _index_factory, _embed
         self._seen_hex = self._seen_raw = False
+        self._key_error: Optional[str] = None
+        self._ops = 0  # add_claim calls seen so far (owned or not): the same number on every rank
         self._searcher: Optional[ShardedSearcher] = None
 
     # -- hooks of the base class -------------------------------------------------------------------------------------
@@ -162,56 +215,204 @@ class ShardedContextGraph(ContextGraph):
             self._index_obj = self._index_factory()  # CPU tests: an oracle-backed stand-in
         return ContextGraph._index.fget(self)
 
-    def _owns(self, h: str) -> bool:
-        # called for every live claim of a sync, on every rank, before ownership decides anything: the key mode has to
-        # follow ALL hashes of the graph, not just this rank's, or the ranks' keys would not be comparable
+    def _observe_hash(self, h) -> None:
+        """The key mode has to follow ALL hashes of the graph, not just this rank's, or the ranks' keys would not be
+        comparable.  Problems are kept for the next query, which raises them on every rank before any collective."""
         if isinstance(h, str) and _HEX64.match(h):
             self._seen_hex = True
         elif self._raw_key(h) is not None:
             self._seen_raw = True
         else:
-            raise ValueError(f"claim-sharded graph: hash {h!r} is neither 64 hex chars nor <= 32 UTF-8 bytes without NUL")
-        if self._seen_hex and self._seen_raw:
-            raise ValueError("claim-sharded graph: 64-hex hashes and short free-form hashes cannot be mixed "
-                             "(their 32-byte keys would not order like the strings)")
+            self._key_error = f"claim-sharded graph: hash {h!r} is neither 64 hex chars nor <= 32 UTF-8 bytes without NUL"
+        if self._seen_hex and self._seen_raw and self._key_error is None:
+            self._key_error = ("claim-sharded graph: 64-hex hashes and short free-form hashes cannot be mixed "
+                               "(their 32-byte keys would not order like the strings)")
         self._key_mode = "hex" if self._seen_hex else "raw"
-        return owner_of(h, self.world) == self.rank
+
+    def _owns(self, h: str) -> bool:
+        self._observe_hash(h)  # also reached by claims put into ``claims`` by hand
+        return isinstance(h, str) and owner_of(h, self.world) == self.rank
+
+    def add_claim(self, claim_hash, text, tags, evidence=None, *, created_ms=None, parent_hash=None) -> None:
+        """lb/context_graph.py:60-82, SPMD: every rank is called, the owner stores.  Pass ``created_ms`` (with None the
+        owner's clock stamps the claim, as the reference's single process would)."""
+        with self._lock:
+            self._ops += 1
+            self._observe_hash(claim_hash)
+            self._tagmask(list(tags))  # tag bits are handed out in first-seen order: the same table on every rank
+            if not (isinstance(claim_hash, str) and owner_of(claim_hash, self.world) == self.rank):
+                return
+            self._next_seq = max(self._next_seq, self._ops)  # a NEW key's dict position, comparable across ranks
+            super().add_claim(claim_hash, text, tags, evidence, created_ms=created_ms, parent_hash=parent_hash)
+
+    def retract(self, claim_hash) -> None:
+        """lb/context_graph.py:84-89, SPMD: a no-op on the ranks that do not own the claim."""
+        with self._lock:
+            if isinstance(claim_hash, str) and owner_of(claim_hash, self.world) == self.rank:
+                super().retract(claim_hash)
 
     def _hash_of_key(self, key: np.ndarray) -> str:
         b = bytes(key)
         return b.hex() if self._key_mode == "hex" else b.rstrip(b"\x00").decode("utf-8", "surrogatepass")
 
-    def _rank(self, query, top_k, since_ms, tags, stats=None) -> Tuple[List[str], List[float]]:
-        """Collective: every rank must call it with the same arguments."""
+    # -- exchanges -----------------------------------------------------------------------------------------------------
+    def _allgather_obj(self, obj) -> list:
+        """Every rank's (JSON-able) ``obj``, rank-major.  Collective."""
+        import json
+        if self._comm is not None:
+            return [json.loads(b.decode("utf-8", "surrogatepass")) for b in
+                    self._comm.allgather(json.dumps(obj).encode("utf-8", "surrogatepass"))]
+        if self.world == 1 and self._group is None:
+            return [json.loads(json.dumps(obj))]
+        import torch.distributed as dist
+        out = [None] * self.world
+        dist.all_gather_object(out, obj, group=self._group)
+        return out
+
+    def _prepare(self, since_ms, tags):
+        """The rank-local phase ahead of a search: reconcile, filters.  -> (since, tag_mask)."""
+        if self._key_error is not None:
+            raise ValueError(self._key_error)
+        self._sync()
+        if self._key_error is not None:  # a hash put into ``claims`` by hand
+            raise ValueError(self._key_error)
+        self._mark_scored(since_ms, tags)
+        since, tag_mask, empty = self._filters(since_ms, tags)
+        if empty:  # nothing on ANY rank can pass (same tag table everywhere): still take part in the exchange
+            since, tag_mask = _hip_int64_max(), 0
+        return since, tag_mask
+
+    def _rank_many(self, queries: Sequence[str], top_k, since_ms, tags, stats=None) -> List[Tuple[List[str], List[float]]]:
+        """Collective: every rank must call it with the same arguments.  -> [(hashes, fp64 scores)] per query."""
         from . import _hip
         with self._lock:
-            self._sync()
-            self._mark_scored(since_ms, tags)
             k = max(0, int(top_k))
-            since, tag_mask, empty = self._filters(since_ms, tags)
-            index = self._index
-            if k == 0:
-                return [], []  # on every rank alike: no exchange for an empty request
-            if empty:  # nothing on THIS rank can pass (no claim of this shard carries the tag): still take part in the exchange
-                since, tag_mask = _hip.INT64_MAX, 0
-            qv = (self._embed_fn or (lambda t: _hip.embed_batch([t])[0]))(query)
+            if k == 0 or not queries:
+                return [([], []) for _ in queries]  # on every rank alike: no exchange for an empty request
+            embed = self._embed_fn or (lambda t: _hip.embed_batch([t])[0])
             if self._comm is not None:
-                _, scores, keys = index.search_sharded(self._comm, qv, k, since, tag_mask, stats, gid_mul=1, gid_add=0)
+                # failures of this phase are the same on every rank (bad hashes, tag overflow) or fatal for the device;
+                # a rank that dies here is noticed by its peers' bounded wait inside liblbhip (coll_timeout_ms)
+                since, tag_mask = self._prepare(since_ms, tags)
+                index = self._index
+                if len(queries) == 1:
+                    _, scores, keys = index.search_sharded(self._comm, embed(queries[0]), k, since, tag_mask, stats, gid_mul=1, gid_add=0)
+                    per_query = [(scores, keys)]
+                else:
+                    qv = np.stack([embed(q) for q in queries]) if self._embed_fn else _hip.embed_batch(list(queries))
+                    _, sc, ky, cnt = index.search_sharded_many(self._comm, qv, k, since, tag_mask, stats, gid_mul=1, gid_add=0)
+                    per_query = [(sc[j, : int(cnt[j])], ky[j, : int(cnt[j])]) for j in range(len(queries))]
             else:
+                # torch.distributed (gloo) has no bounded wait of ours: a rank whose local phase raises must still send
+                failed, since, tag_mask, qv = None, 0, 0, [None] * len(queries)
+                try:
+                    since, tag_mask = self._prepare(since_ms, tags)
+                    qv = [embed(q) for q in queries]
+                except Exception as e:  # noqa: BLE001
+                    failed = e
                 if self._searcher is None:
-                    self._searcher = ShardedSearcher(self._local_search, self.rank, self.world, group=self._group, always_gather=True)
-                _, scores, kw = self._searcher.search(qv, k, since, tag_mask)
-                keys = np.ascontiguousarray(kw).astype(">u8").view(np.uint8).reshape(-1, 32)
-            return [self._hash_of_key(keys[i]) for i in range(len(scores))], [float(x) for x in scores]
+                    self._searcher = ShardedSearcher(self._local_search, self.rank, self.world, group=self._group,
+                                                     always_gather=self.world > 1 or self._group is not None)
+                res = self._searcher.search_many(qv, k, since, tag_mask, failed=failed)
+                per_query = [(scores, np.ascontiguousarray(kw).astype(">u8").view(np.uint8).reshape(-1, 32)) for _, scores, kw in res]
+            return [([self._hash_of_key(keys[i]) for i in range(len(scores))], [float(x) for x in scores])
+                    for scores, keys in per_query]
+
+    def _rank(self, query, top_k, since_ms, tags, stats=None) -> Tuple[List[str], List[float]]:
+        return self._rank_many([query], top_k, since_ms, tags, stats)[0]
 
     def _local_search(self, q, k, since_ms, tag_mask):
         if not self._id_of:
             return np.zeros(0, np.uint64), np.zeros(0), np.zeros((0, 32), np.uint8)
         return self._index.search_shard(q, k, since_ms, tag_mask)
 
-    def compile_many(self, queries: Sequence[str], *, top_k: int = 8, since_ms=None, tags=None, lazy: bool = False):
-        """Collective; one exchange per query (the batched MFMA path is per GPU and has no sharded form yet)."""
-        return [self.compile(q, top_k=top_k, since_ms=since_ms, tags=tags, lazy=lazy) for q in queries]
+    def _fetch(self, hashes: Sequence[str]) -> dict:
+        """hash -> stored claim dict (``Claim.to_dict``) for claims owned by ANY rank: the owners hand them to everybody in
+        one small exchange (k entries).  Collective."""
+        with self._lock:
+            mine = {h: self.claims[h].to_dict() for h in set(hashes) if h in self.claims}
+        out: dict = {}
+        for part in self._allgather_obj(mine):
+            out.update(part)
+        return out
 
-    def recent(self, since_ms, limit=100):
-        raise NotImplementedError("get_recent_claims is not sharded: ask a single-GPU ContextGraph")
+    def _format(self, query: str, chosen: List[str]) -> str:
+        got = self._fetch(chosen)
+        return format_context(query, [(got[h]["text"], got[h]["tags"]) for h in chosen])
+
+    def _lazy(self, query: str, chosen: List[str]) -> LazyContext:
+        got = self._fetch(chosen)  # the exchange cannot be deferred: it is collective; the formatting is
+        return LazyContext(query, chosen, [(got[h]["text"], tuple(got[h]["tags"])) for h in chosen])
+
+    def compile_many(self, queries: Sequence[str], *, top_k: int = 8, since_ms=None, tags=None, lazy: bool = False):
+        """Collective.  The batch is ranked in ONE local pass per rank (K3 on the matrix cores) and ONE exchange of all
+        the lists (``lbh_index_search_sharded_many``); one more small exchange hands out the winners' text and tags."""
+        queries = list(queries)
+        ranked = [hs for hs, _ in self._rank_many(queries, top_k, since_ms, tags)]
+        got = self._fetch([h for hs in ranked for h in hs]) if queries else {}
+        pairs = [[(got[h]["text"], tuple(got[h]["tags"])) for h in hs] for hs in ranked]
+        if lazy:
+            return [LazyContext(q, hs, pr) for q, hs, pr in zip(queries, ranked, pairs)]
+        return [(format_context(q, pr), hs) for q, hs, pr in zip(queries, ranked, pairs)]
+
+    # -- recency query (lb/node.py:736-762) ---------------------------------------------------------------------------
+    def _recent_entries(self, since_ms, limit) -> List[list]:
+        """Global newest-first list of [created_ms, dict-position stamp, hash]: every rank's local list (the device's
+        masked top-``limit`` on its shard), gathered and merged by (created desc, stamp asc).  Collective."""
+        import operator
+        if limit is not None:
+            limit = operator.index(limit)
+        with self._lock:
+            # a non-negative limit bounds what each rank has to send; None / negative limits need every match
+            local_limit = limit if (limit is not None and limit >= 0) else None
+            hs = ContextGraph.recent(self, since_ms, local_limit)
+            mine = [[int(self.claims[h].created_ms), int(self._seq_of[h]), h] for h in hs]
+        merged = [e for part in self._allgather_obj(mine) for e in part]
+        merged.sort(key=lambda e: (-e[0], e[1]))
+        return merged[:limit]
+
+    def recent(self, since_ms, limit: Optional[int] = 100) -> List[str]:
+        return [e[2] for e in self._recent_entries(since_ms, limit)]
+
+    def recent_claims(self, since_ms, limit: Optional[int] = 100) -> List[dict]:
+        hs = self.recent(since_ms, limit)
+        got = self._fetch(hs)
+        return [_recent_dict(got[h]) for h in hs]
+
+    # -- snapshot (lb/context_graph.py:135-148) ------------------------------------------------------------------------
+    def snapshot(self) -> dict:
+        """Collective: the reference's snapshot of the WHOLE graph (every rank's claims, in the order a single graph's
+        dict would hold them), identical on every rank."""
+        with self._lock:
+            mine = [[int(self._seq_of.get(h, 0)), h, c.to_dict()] for h, c in self.claims.items()]
+        rows = sorted((e for part in self._allgather_obj(mine) for e in part), key=lambda e: e[0])
+        return {"claims": {h: d for _, h, d in rows}}
+
+    @staticmethod
+    def from_snapshot_sharded(s: dict, rank: int, world: int, **kw) -> "ShardedContextGraph":
+        """``from_snapshot`` for one rank: every rank reads the same snapshot and keeps the claims it owns (re-vectorised
+        in one K1 launch at its first query, like the single-GPU loader)."""
+        from .context_graph import Claim
+        g = ShardedContextGraph(rank, world, **kw)
+        for h, cd in (s.get("claims", {}) or {}).items():
+            g._ops += 1
+            g._observe_hash(h)
+            c = Claim.from_dict(cd)
+            g._tagmask(list(c.tags))
+            if isinstance(h, str) and owner_of(h, world) == rank:
+                g._next_seq = max(g._next_seq, g._ops)
+                g.claims[h] = c
+                if not c.retracted:
+                    g._pending_text[h] = c.text
+        return g
+
+
+def _hip_int64_max() -> int:
+    from . import _hip
+    return _hip.INT64_MAX
+
+
+def _recent_dict(d: dict) -> dict:
+    """The dict literal of lb/node.py:753-760 from a stored claim dict."""
+    return {"claim_hash": d["claim_hash"], "text": d["text"], "tags": list(d["tags"]), "created_ms": d["created_ms"],
+            "parent_hash": d.get("parent_hash")}

@@ -14,6 +14,7 @@ class OracleIndex:
         self.tags = np.zeros(0, dtype=np.uint64)
         self.keys = np.zeros((0, 32), dtype=np.uint8)
         self.live = np.zeros(0, dtype=bool)
+        self.order = np.zeros(0, dtype=np.uint64)
 
     def reserve(self, n):
         pass
@@ -29,6 +30,7 @@ class OracleIndex:
         self.tags = np.concatenate([self.tags, np.zeros(n, np.uint64) if tagmask is None else np.asarray(tagmask, dtype=np.uint64)])
         self.keys = np.concatenate([self.keys, np.asarray(keys, dtype=np.uint8).reshape(-1, 32)])
         self.live = np.concatenate([self.live, np.ones(n, dtype=bool)])
+        self.order = np.concatenate([self.order, np.arange(first, first + n, dtype=np.uint64)])  # default: the claim id
         return np.arange(first, first + n, dtype=np.uint64)
 
     def add_texts(self, blob, offsets, created_ms, tagmask, keys):
@@ -49,6 +51,16 @@ class OracleIndex:
 
     def set_keys(self, ids, keys):
         self.keys[np.asarray(ids, dtype=np.int64)] = np.asarray(keys, dtype=np.uint8).reshape(-1, 32)
+
+    def set_order(self, ids, order):
+        self.order[np.asarray(ids, dtype=np.int64)] = np.asarray(order, dtype=np.uint64)
+
+    def recent(self, since_ms=_hip.SINCE_NONE, limit=100, stats=None):
+        """lbh_index_recent: live claims with created_ms >= since_ms, newest first, ties in ascending order stamp."""
+        ok = self.live & (self.created >= max(int(since_ms), _hip.SINCE_NONE))
+        idx = np.nonzero(ok)[0]
+        idx = idx[np.lexsort((self.order[idx], -self.created[idx]))][: max(0, int(limit))]
+        return idx.astype(np.uint64), self.created[idx].copy(), int(ok.sum())
 
     def get_embedding(self, cid):
         return self.emb[int(cid)].copy()

@@ -33,9 +33,23 @@ def test_gpus_flag_launches_that_many_ranks_cpu_rehearsal():
     assert r.returncode == 0, r.stderr[-2000:]
     line = _json_line(r.stdout)
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["warmup"] == 2 and line["scaling"] == "weak"
-    assert line["config"]["claims_per_gpu"] == 1500
+    assert line["config"]["claims_per_gpu"] == 1500 and line["config"]["claims_total"] == 3000
     assert 2 * 1500 * 0.97 <= line["config"]["live_claims_total"] <= 2 * 1500  # both ranks' live claims, ~1 % retracted
     assert "REHEARSAL" in line["data"]
+
+
+@pytest.mark.timeout(300)
+def test_strong_scaling_splits_one_corpus_cpu_rehearsal():
+    """--scaling strong: --claims is the TOTAL, dealt out in N contiguous parts; said so on the line."""
+    cmd = [sys.executable, HARNESS, "--gpus", "3", "--scaling", "strong", "--claims", "3001", "--steps", "4", "--warmup", "1",
+           "--queries", "3", "--cpu-sample", "0"]
+    r = subprocess.run(cmd, env=_env(LBM_BENCH_REHEARSE_GLOO="1"), capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 3 and line["scaling"] == "strong"
+    assert line["config"]["claims_total"] == 3001 and line["config"]["claims_per_gpu"] == 1000  # rank 0's part
+    assert 3001 * 0.97 <= line["config"]["live_claims_total"] <= 3001
+    assert "in total" in line["config"]["workload"] and "strong scaling" in line["config"]["workload"]
 
 
 @pytest.mark.timeout(120)

@@ -426,13 +426,25 @@ def test_group_graph_save_load_and_rebuild(hip, tmp_path, golden_snapshot):
         elif op[0] == "retract":
             txs.append({"type": "retract", "claim_hash": op[1]})
             og.retract(op[1])
-    txs.append({"type": "claim", "artifact_hash": "missing-from-cas", "object": None})
+    txs.append({"type": "claim", "artifact_hash": "missing-from-cas"})  # no object at all: cas.has(h) is False, skipped
     txs.append({"type": "vote", "x": 1})
+    # lb/node.py:498-509: `cas.get_json(h) or {}` makes a falsy object an EMPTY claim; anything that raises while the
+    # claim is rebuilt (a truthy non-dict, created_ms = Infinity, tags that cannot be listed) skips that claim only
+    e1, e2, bad = "e" * 64, "f" * 64, "b" * 63
+    txs.append({"type": "claim", "artifact_hash": e1, "object": None})
+    og.add_claim(e1, "", [], created_ms=0)
+    txs.append({"type": "claim", "artifact_hash": e2, "object": {"text": 12, "created_ms": None}})
+    og.add_claim(e2, "12", [], created_ms=0)
+    txs.append({"type": "claim", "artifact_hash": bad + "1", "object": ["not", "a", "dict"]})
+    txs.append({"type": "claim", "artifact_hash": bad + "2", "object": {"text": "gamma", "created_ms": float("inf")}})
+    txs.append({"type": "claim", "artifact_hash": bad + "3", "object": {"text": "gamma", "tags": 7}})
+    txs.append({"type": "claim", "artifact_hash": 17, "object": {"text": "gamma"}})
     old = node.groups["g1"].graph
     node.rebuild_group_graph("g1", txs)
     assert node.groups["g1"].graph is not old
-    for q in ("beta", "gamma delta", ""):
-        assert node.compile_context("g1", q, top_k=10) == og.compile(q, top_k=10)
+    assert set(node.groups["g1"].graph.claims) == set(og.claims)
+    for q in ("beta", "gamma delta", "", "12"):
+        assert node.compile_context("g1", q, top_k=20) == og.compile(q, top_k=20)
 
 
 def test_ingest_from_pinned_buffers_equals_pageable(hip):

@@ -1,0 +1,155 @@
+"""Round-3 GPU tests: the batched claim-sharded search (lbh_index_search_sharded_many), failure containment and the
+bounded wait of the sharded searches, lbh_comm_allgather, and the claim-sharded graph's batched / recency / snapshot
+entries on the real backend -- all with a one-rank RCCL communicator (the box has one GPU).  Bit-exact, through the C ABI."""
+import numpy as np
+import pytest
+
+from oracle import lb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from lbm_amd import _hip
+    assert "gfx950" in _hip.device_name()
+    return _hip
+
+
+@pytest.fixture(scope="module")
+def shard(hip):
+    from lbm_amd import synth
+    ch = synth.make_chunk(0, 120_000, seed=19, real_sha_keys=False, dup_frac=0.01)
+    ix = hip.Index()
+    ids = ix.add_texts(ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)
+    ix.retract_many(ids[ch.retracted])
+    comm = hip.Comm(hip.comm_unique_id(), 0, 1)
+    yield ch, ix, comm
+    comm.close()
+    ix.close()
+
+
+def test_sharded_many_equals_index_search_single_rank(hip, shard):
+    """Local K3 pass -> per-query lists -> ONE all-gather -> merges must give exactly lbh_index_search's answers (and the
+    single-query sharded entry's keys), for batches that take the matrix-core path, the paged path (k > 64), the
+    all-ties query that falls back to the exact scan, filters, and batches of one and two queries."""
+    from lbm_amd import synth
+    ch, ix, comm = shard
+    qv = hip.embed_batch(synth.make_queries(37, seed=5) + [ch.text(5), ""])
+    p50 = int(ch.created_ms[ch.n // 2])
+    st = hip.Stats()
+    for nq in (39, 1, 2, 3):
+        for k, since, tm in ((8, hip.SINCE_NONE, 0), (64, p50, 0), (5, hip.SINCE_NONE, 0xF0F0), (100, hip.SINCE_NONE, 0), (0, p50, 0)):
+            q = qv[-nq:]
+            wi, ws, wc = ix.search(q, k, since, tm)
+            gi, gs, gk, gc = ix.search_sharded_many(comm, q, k, since, tm, st, gid_mul=1, gid_add=0)
+            assert gc.tolist() == wc.tolist(), (nq, k)
+            for j in range(nq):
+                c = int(wc[j])
+                assert gi[j, :c].tolist() == wi[j, :c].tolist(), (nq, k, j)
+                assert gs[j, :c].tobytes() == ws[j, :c].tobytes()
+                if k and j in (0, nq - 1):
+                    _, _, sk = ix.search_sharded(comm, q[j], k, since, tm)
+                    assert gk[j, :c].tobytes() == sk.tobytes()
+            if nq >= 3 and 0 < k <= 64:
+                assert st.path == 2 and st.rows_scanned >= ix.size()  # the batch really took the matrix-core pass
+    gi, _, _, _ = ix.search_sharded_many(comm, qv[:4], 8, gid_mul=8, gid_add=5)
+    wi, _, _ = ix.search(qv[:4], 8)
+    assert gi.tolist() == (wi * 8 + 5).tolist()
+
+
+def test_sharded_many_against_the_oracle(hip, shard):
+    """... and once against the CPU oracle itself (hash keys included), so the chain of equalities ends in the reference."""
+    from lbm_amd import synth
+    ch, ix, comm = shard
+    n = 20_000
+    small = hip.Index()
+    small.add_texts(ch.blob[: ch.offsets[n] + 1], ch.offsets[: n + 1], ch.created_ms[:n], ch.tagmask[:n], ch.keys[:n])
+    emb = orc.embed_batch_packed(ch.blob[: ch.offsets[n] + 1], ch.offsets[: n + 1])
+    hexes = [bytes(r).hex() for r in ch.keys[:n]]
+    qs = synth.make_queries(6, seed=8) + [""]
+    qv = hip.embed_batch(qs)
+    for k, since, tm in ((8, None, 0), (64, int(ch.created_ms[n // 3]), 0xFF)):
+        gi, gs, gk, gc = small.search_sharded_many(comm, qv, k, hip.SINCE_NONE if since is None else since, tm, gid_mul=1, gid_add=0)
+        for j, q in enumerate(qs):
+            oi, osc = orc.compile_arrays(emb, ch.created_ms[:n], np.zeros(n, np.uint8), hexes, orc.embed_array(q), k, since, ch.tagmask[:n], tm)
+            c = int(gc[j])
+            assert gi[j, :c].tolist() == oi.tolist() and gs[j, :c].tobytes() == osc.tobytes(), (k, j)
+            assert gk[j, :c].tobytes() == ch.keys[:n][oi].tobytes()
+    small.close()
+
+
+def test_local_failure_still_reaches_the_all_gather(hip, shard):
+    """Failure containment: a rank whose LOCAL search fails must not leave before the all-gather (its peers would wait
+    inside it for ever).  The injected fault makes this rank's local part fail; the call still runs the exchange -- the
+    list's count word carries the error -- returns an error, and the communicator stays usable."""
+    ch, ix, comm = shard
+    q = hip.embed_batch(["w00001 w00002"])[0]
+    want = ix.search_shard(q, 8)
+    for call in (lambda: ix.search_sharded(comm, q, 8), lambda: ix.search_sharded(comm, q, 100),
+                 lambda: ix.search_sharded_many(comm, np.stack([q] * 5), 8)):
+        hip.set_option("inject_fault", 1)
+        with pytest.raises(hip.HipBackendError, match="injected fault"):
+            call()
+        gi, gs, _ = ix.search_sharded(comm, q, 8)  # next call: business as usual
+        assert gi.tolist() == want[0].tolist() and gs.tobytes() == want[1].tobytes()
+
+
+def test_a_missing_peer_ends_in_a_timeout_not_a_hang(hip, shard):
+    """A peer that never reaches the all-gather is played by a host function that holds this rank's stream up for four
+    times the timeout: the call must come back with an error after ~coll_timeout_ms, and the communicator must refuse
+    further collectives (the queued one is still unfinished behind it)."""
+    import time
+    ch, ix, _ = shard
+    comm = hip.Comm(hip.comm_unique_id(), 0, 1)  # its own communicator: it ends up broken
+    q = hip.embed_batch(["w00003"])[0]
+    hip.set_option("coll_timeout_ms", 150)
+    try:
+        hip.set_option("inject_fault", 2)
+        t0 = time.perf_counter()
+        with pytest.raises(hip.HipBackendError, match="no completion after 150 ms"):
+            ix.search_sharded(comm, q, 8)
+        assert 0.1 < time.perf_counter() - t0 < 0.55
+        with pytest.raises(hip.HipBackendError, match="unusable"):
+            ix.search_sharded(comm, q, 8)
+        with pytest.raises(hip.HipBackendError, match="unusable"):
+            ix.search_sharded_many(comm, np.stack([q] * 4), 8)
+        time.sleep(0.7)  # the sleeping host function returns, the stream drains: the index itself is fine
+        assert ix.search_shard(q, 8)[0].shape[0] == 8
+    finally:
+        hip.set_option("coll_timeout_ms", 60000)
+        hip.set_option("inject_fault", 0)
+        comm.close()
+
+
+def test_comm_allgather_bytes(hip, shard):
+    _, _, comm = shard
+    for payload in (b"", b"x", bytes(range(256)) * 300):
+        assert comm.allgather(payload) == [payload]
+
+
+def test_sharded_graph_batched_recent_snapshot_single_rank(hip, golden_synth):
+    """ShardedContextGraph on the real backend (one-rank RCCL communicator): compile_many through
+    lbh_index_search_sharded_many, the winners' text through lbh_comm_allgather, the recency query and the gathered
+    snapshot -- against the oracle graph."""
+    from lbm_amd.sharded import ShardedContextGraph
+    d = golden_synth
+    comm = hip.Comm(hip.comm_unique_id(), 0, 1)
+    try:
+        g, og = ShardedContextGraph(0, 1, comm=comm), orc.OracleGraph()
+        for i in range(600):
+            tags = ["t%02d" % j for j in range(64) if (d["tagmask"][i] >> j) & 1]
+            for gg in (g, og):
+                gg.add_claim(d["hashes"][i], d["texts"][i], tags, created_ms=d["created_ms"][i // 3 * 3])
+        for i in range(0, 600, 37):
+            g.retract(d["hashes"][i]); og.retract(d["hashes"][i])
+        qs = ["w00001 w00004", "w00002", "", d["texts"][7], "w00010 w00003 w00001"]
+        for kw in ({"top_k": 8}, {"top_k": 70, "since_ms": d["created_ms"][300]}, {"top_k": 5, "tags": ["t03", "t07"]}, {"top_k": 0}):
+            assert g.compile_many(qs, **kw) == [og.compile(q, **kw) for q in qs], kw
+            assert g.compile(qs[0], **kw) == og.compile(qs[0], **kw)
+        for since, limit in ((0, 100), (d["created_ms"][300], 7), (0, None), (0, -590), (10 ** 18, 5)):
+            want = orc.recent_claims(og.claims, since, limit)
+            assert g.recent_claims(since, limit) == want, (since, limit)
+        assert g.snapshot() == og.snapshot()
+    finally:
+        comm.close()

@@ -143,6 +143,10 @@ def _graph_worker(rank, world, port, out_q):
                   and [float(x).hex() for x in sc] == r["scores"])
     owned = sum(owner_of(h, world) == rank for h, r in zip(d["hashes"], d["retracted"]) if not r)
     ok.append(g._index.size() == owned and 0 < owned < d["n"])  # only this rank's claims are on its device
+    # ... and on its host: per-rank state is ~ N / world (Claim objects, id maps), not N
+    owned_all = sum(owner_of(h, world) == rank for h in d["hashes"])
+    ok.append(len(g.claims) == owned_all and len(g._id_of) == owned and len(g._meta) == owned and len(g._seq_of) == owned_all)
+    ok.append(owned_all < 1.5 * d["n"] / world + 50)
     # the tag extension and a lazily formatted result go through the same exchange
     og = orc.OracleGraph()
     for i in range(0, 300):
@@ -156,6 +160,45 @@ def _graph_worker(rank, world, port, out_q):
     lazy = g2.compile("w00003", top_k=4, lazy=True)
     ok.append(lazy.claim_hashes == og.compile("w00003", top_k=4)[1] and tuple(lazy) == og.compile("w00003", top_k=4))
     ok.append(g2.compile_many(["w00001", ""], top_k=3) == [og.compile("w00001", top_k=3), og.compile("", top_k=3)])
+    # a batch goes through ONE exchange of all its lists (ShardedSearcher.search_many)
+    qs = ["w00001 w00004", "w00002", "", "w00010 w00003 w00001", d["texts"][7]]
+    for kw in ({"top_k": 8}, {"top_k": 70, "since_ms": d["created_ms"][150]}, {"top_k": 5, "tags": ["t03", "t07"]}, {"top_k": 0}):
+        ok.append(g2.compile_many(qs, **kw) == [og.compile(q, **kw) for q in qs])
+    lz = g2.compile_many(qs[:2], top_k=4, lazy=True)
+    ok.append([tuple(x) for x in lz] == [og.compile(q, top_k=4) for q in qs[:2]])
+    # the recency query (lb/node.py:736-762): merge of the ranks' newest-first lists; ties keep the dict order, which a
+    # re-added hash does not change
+    for h in (d["hashes"][5], d["hashes"][17]):
+        og.retract(h); g2.retract(h)
+    og.add_claim(d["hashes"][3], "re-added text", ["t01"], created_ms=d["created_ms"][40])
+    g2.add_claim(d["hashes"][3], "re-added text", ["t01"], created_ms=d["created_ms"][40])
+    for i in (290, 291, 292):  # equal timestamps: the stable sort keeps insertion order
+        og.add_claim("%064x" % i, "tie %d" % i, [], created_ms=d["created_ms"][100])
+        g2.add_claim("%064x" % i, "tie %d" % i, [], created_ms=d["created_ms"][100])
+    for since, limit in ((0, 100), (d["created_ms"][100], 7), (d["created_ms"][100], 1000), (d["created_ms"][250], None),
+                         (0, -290), (0, 0), (10 ** 18, 5)):
+        want = orc.recent_claims(og.claims, since, limit)
+        ok.append(g2.recent(since, limit) == [w["claim_hash"] for w in want] and g2.recent_claims(since, limit) == want)
+    ok.append(g2.snapshot() == og.snapshot())
+    g4 = ShardedContextGraph.from_snapshot_sharded(og.snapshot(), rank, world, _index_factory=OracleIndex, _embed=orc.embed_array)
+    ok.append(g4.compile("w00001 w00002", top_k=16) == og.compile("w00001 w00002", top_k=16) and g4.snapshot() == og.snapshot()
+              and g4.recent(0, 9) == [w["claim_hash"] for w in orc.recent_claims(og.claims, 0, 9)])
+    # failure containment: rank 1's local search raises -> it still takes part in the exchange, EVERY rank raises for
+    # that query (nobody waits inside the all-gather), and the next query works
+    from lbm_amd.sharded import ShardPeerError
+    real = g2._index.search_shard
+    if rank == 1:
+        def boom(*a, **k):
+            raise RuntimeError("injected: local search failed on rank 1")
+        g2._index.search_shard = boom
+    for call in (lambda: g2.compile("w00001", top_k=4), lambda: g2.compile_many(qs, top_k=4)):
+        try:
+            call()
+            ok.append(False)
+        except RuntimeError as e:
+            ok.append(isinstance(e, ShardPeerError) != (rank == 1))
+    g2._index.search_shard = real
+    ok.append(g2.compile("w00001", top_k=4) == og.compile("w00001", top_k=4))
     # short free-form hashes (the reference's tests use "old" / "new"): raw keys, still mergeable
     g3, og3 = ShardedContextGraph(rank, world, _index_factory=OracleIndex, _embed=orc.embed_array), orc.OracleGraph()
     for i, h in enumerate(["old", "new", "h1", "zzz", "Zzz", "a", "aa", "é", "claim_0002", "claim_0001"]):

@@ -23,12 +23,13 @@ def _corpus(hip, torch, rng, n):
     words = keys.view(">u8").astype(np.uint64).view(np.int64).reshape(n, 4)  # word w = big-endian value of key bytes 8w..8w+7
     cols = {"e64": t64, "e32": t64.to(torch.float32), "ms": torch.from_numpy(ms).to(dev),
             "tags": torch.from_numpy(tags.view(np.int64)).to(dev), "keys": torch.from_numpy(words.copy()).to(dev)}
-    return ix, cols
+    return ix, cols, (v, ms, tags, keys)
 
 
 def _noalloc(hip, torch, cols, n, q, k, since, tm, out):
     rows, scores, count = out
     count.fill_(-7)
+    torch.cuda.synchronize()  # the call runs on the library's own stream: nothing else orders this fill ahead of it
     hip.search_dev_noalloc(cols["e32"].data_ptr(), cols["e64"].data_ptr(), cols["ms"].data_ptr(), cols["tags"].data_ptr(),
                            cols["keys"].data_ptr(), n, 1.0, q, k, since, tm, rows.data_ptr(), scores.data_ptr(), count.data_ptr())
     c = int(count.item())
@@ -46,8 +47,16 @@ def test_noalloc_entry_point_equals_search_shard():
     qs /= np.linalg.norm(qs, axis=1, keepdims=True)
     # two calls in a row, the second on a smaller input; then a large one again, then a tiny one
     for n in (300_000, 4_000, 120_000, 70):
-        ix, cols = _corpus(hip, torch, rng, n)
+        ix, cols, (v, ms, tags, keys) = _corpus(hip, torch, rng, n)
         st = hip.Stats()
+        if n <= 4_000:  # and once against the CPU oracle itself, so that this file stands on its own
+            from oracle import lb_oracle as orc
+            hexes = [bytes(r).hex() for r in keys]
+            for q in (qs[0], np.zeros(64)):
+                for k, since, tm in ((8, None, 0), (64, 5000, 0xFF)):
+                    oi, osc = orc.compile_arrays(v, ms, np.zeros(n, np.uint8), hexes, q, k, since, tags, tm)
+                    gi, gs, c = _noalloc(hip, torch, cols, n, q, k, hip.SINCE_NONE if since is None else since, tm, out)
+                    assert c == len(oi) and gi.tolist() == oi.tolist() and gs.tobytes() == osc.tobytes(), (n, k, since, tm)
         for q in list(qs) + [np.zeros(64)]:  # the zero query ties every row at 0.0: the exact fp64 path must take over
             for k, since, tm in ((8, hip.SINCE_NONE, 0), (64, 5000, 0), (8, hip.SINCE_NONE, 0xFF), (1, 9000, 0xF0F0), (0, hip.SINCE_NONE, 0)):
                 wi, ws, _ = ix.search_shard(q, k, since, tm, st)
