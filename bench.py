@@ -164,8 +164,12 @@ def vectorise_roofline(k1, claims, t_add, t_add_first, chunk, n_chunks):
         import glob
         pmc = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_k1.json")))
         with open(pmc[-1]) as f:
-            per_claim = float(json.load(f)["embed_kernel"]["valu_wave_instructions_per_claim"])
+            ek = json.load(f)["embed_kernel"]
+        per_claim = float(ek["valu_wave_instructions_per_claim"])
         out["valu_wave_instructions_per_claim"] = per_claim
+        # same pass: share of SIMD-cycles with a vector instruction executing (these integer instructions occupy the pipe
+        # for ~4 cycles each, so the pipe is busier than the 2-cycle issue model says)
+        out["valu_busy_fraction_pmc"] = ek.get("valu_busy_fraction")
         out["instructions_source"] = f"profiles/{os.path.basename(pmc[-1])} (SQ_INSTS_VALU / claims, same corpus); not measured in this run"
         out["achieved"] = per_claim * out["kernel_claims_per_s"]
         out["frac"] = out["achieved"] / VALU_ISSUE_PER_S

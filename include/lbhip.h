@@ -82,7 +82,8 @@ int lbh_device_name(lbh_ctx* ctx, char* buf, int buflen);
  * use, wider candidate margin, unit-scale data only - results are the same either way, the
  * re-rank is always exact fp64), "bq_mode" (batched scan precision: 0 fp32 MFMA, 1 split bf16,
  * 2 fp16 = default), "spin_us" (completion-ticket polling budget), "coll_timeout_ms" (longest wait for a
- * claim-sharded search's all-gather; also LBH_COLL_TIMEOUT_MS), "inject_fault" (test hook, one-shot: 1 = the next
+ * claim-sharded search's all-gather; also LBH_COLL_TIMEOUT_MS), "force_exact" (0/1, diagnostic: single-query searches rank with the exact fp64 scan only -- the
+ * path that otherwise serves mass ties and result pages beyond the first), "inject_fault" (test hook, one-shot: 1 = the next
  * sharded search's local part fails on this rank, 2 = its stream is held up past the timeout).  Also read from the
  * environment at lbh_init as LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT / LBH_SCAN_MODE /
  * LBH_BQ_MODE / LBH_SPIN_US; environment only: LBH_SCAN_SPLIT ("a,b,c,d": tile shares of the scan's

@@ -64,6 +64,7 @@ struct lbh_ctx {
                          // 2 = one fp16 product (a third of the matrix work, margin 2.2e-3)
     int spin_us = 5000;  // poll the completion ticket this long before blocking in hipStreamSynchronize (0 = always block)
     int coll_timeout_ms = 60000;  // claim-sharded searches: longest wait for the all-gather (a peer that never arrives) before the call fails
+    int force_exact = 0;   // option "force_exact" (diagnostic / parity tests): single-query searches skip the fp32 scan and rank with the exact fp64 scan
     int inject_fault = 0;  // TEST HOOK (option "inject_fault", one-shot): 1 = this rank's local search of the next sharded call fails;
                            // 2 = the next sharded call's stream is held up for 4 x coll_timeout_ms by a sleeping host function
     void* noalloc_scratch = nullptr;  // THIS device's address of search.hip's file-scope scratch array (lbh_search_dev_noalloc)
@@ -579,7 +580,7 @@ int search_loaded(lbh_index* ix, lbh_slot* sl, int64_t k, int64_t since_ms, uint
         while (remaining > 0) {
             const int page = (int)std::min<int64_t>(remaining, LBH_MAX_PAGE);
             PageOut po;
-            int rc = run_page(ix, sl, page, since_ms, tag_mask, true, cur, timing, &po, &acc);
+            int rc = run_page(ix, sl, page, since_ms, tag_mask, !ix->ctx->force_exact, cur, timing, &po, &acc);
             if (rc) return rc;
             for (int i = 0; i < po.count; ++i) {
                 out_ids[got + i] = ix->id_of_row[po.rows[i]];
@@ -776,6 +777,7 @@ int lbh_set_option(lbh_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "bq_mode")) c->bq_mode = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else if (!strcmp(name, "spin_us")) c->spin_us = (int)std::max<int64_t>(0, std::min<int64_t>(1000000, value));
     else if (!strcmp(name, "coll_timeout_ms")) c->coll_timeout_ms = (int)std::max<int64_t>(1, std::min<int64_t>(3600000, value));
+    else if (!strcmp(name, "force_exact")) c->force_exact = value != 0;
     else if (!strcmp(name, "inject_fault")) c->inject_fault = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else return fail(LBH_E_INVALID, "unknown option %s", name);
     return LBH_OK;
