@@ -64,6 +64,7 @@ struct lbh_ctx {
                          // 2 = one fp16 product (a third of the matrix work, margin 2.2e-3)
     int spin_us = 5000;  // poll the completion ticket this long before blocking in hipStreamSynchronize (0 = always block)
     int coll_timeout_ms = 60000;  // claim-sharded searches: longest wait for the all-gather (a peer that never arrives) before the call fails
+    int scan_fuse = 1;     // option "scan_fuse": the scan's last block runs the select step itself -- 0 never, 1 = when the grid is one block per CU (default), 2 always
     int force_exact = 0;   // option "force_exact" (diagnostic / parity tests): single-query searches skip the fp32 scan and rank with the exact fp64 scan
     int inject_fault = 0;  // TEST HOOK (option "inject_fault", one-shot): 1 = this rank's local search of the next sharded call fails;
                            // 2 = the next sharded call's stream is held up for 4 x coll_timeout_ms by a sleeping host function
@@ -237,6 +238,7 @@ int slot_create(lbh_index* ix, int which, lbh_slot** out) {
     HIP_TRY(hipMalloc((void**)&w.xcand_ord, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 8));
     HIP_TRY(hipMalloc((void**)&w.xcand_row, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 4));
     HIP_TRY(hipMalloc((void**)&w.flags, 512));
+    HIP_TRY(hipMalloc((void**)&w.bmax, (size_t)LBH_MAX_BLOCKS * 4));
     HIP_TRY(hipMalloc((void**)&sl->d_off, 16));
     HIP_TRY(hipHostMalloc((void**)&w.result_host, sizeof(lbh_result), hipHostMallocMapped | hipHostMallocCoherent));
     HIP_TRY(hipHostGetDevicePointer((void**)&w.result_dev, w.result_host, 0));
@@ -250,7 +252,7 @@ void slot_destroy(lbh_slot* sl) {
     if (!sl) return;
     if (sl->stream) (void)hipStreamSynchronize(sl->stream);
     lbh_workspace& w = sl->ws;
-    void* dev[] = {w.rc_a, w.rc_b, w.rc_row, w.rc_cnt, w.q64, w.cand, w.xcand_ord, w.xcand_row, w.flags,
+    void* dev[] = {w.rc_a, w.rc_b, w.rc_row, w.rc_cnt, w.q64, w.cand, w.xcand_ord, w.xcand_row, w.flags, w.bmax,
                    w.bq_qmat, w.bq_cand, w.bq_total, w.bq_seed, w.bq_bfrag, sl->d_text, sl->d_off};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -527,7 +529,7 @@ int run_page(lbh_index* ix, lbh_slot* sl, int page, int64_t since_ms, uint64_t t
         if (half && !emb16_current(ix)) return LBH_NEED_EMB16;
         if (fast)
             HIP_TRY(lbh_launch_search_fast(dv, half ? ix->emb16 : nullptr, sl->ws, sl->qptr, sl->qarg, page, has_since, since_ms,
-                                           tag_mask, (half && !has_since && !tag_mask) ? lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu, true) : grid, c->n_cu, c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, e0, e1));
+                                           tag_mask, (half && !has_since && !tag_mask) ? lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu, true) : grid, c->n_cu, c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, e0, e1, nullptr, c->scan_fuse));
         else {
             const int xgrid = std::min(grid, 512);
             HIP_TRY(lbh_launch_search_exact(dv, sl->ws, sl->qptr, sl->qarg, page, has_since, since_ms, tag_mask, cur, xgrid, seq, s, e0, e1));
@@ -730,6 +732,7 @@ int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx) {
     }
     if (const char* e4 = getenv("LBH_BQ_MODE")) c->bq_mode = std::max(0, std::min(2, atoi(e4)));
     if (const char* e3 = getenv("LBH_SPIN_US")) c->spin_us = std::max(0, std::min(1000000, atoi(e3)));
+    if (const char* e8 = getenv("LBH_SCAN_FUSE")) c->scan_fuse = std::max(0, std::min(2, atoi(e8)));
     if (const char* e7 = getenv("LBH_COLL_TIMEOUT_MS")) c->coll_timeout_ms = std::max(1, std::min(3600000, atoi(e7)));
     hipError_t e0 = hipSetDevice(c->device);
     if (e0 == hipSuccess) e0 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -777,6 +780,7 @@ int lbh_set_option(lbh_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "bq_mode")) c->bq_mode = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else if (!strcmp(name, "spin_us")) c->spin_us = (int)std::max<int64_t>(0, std::min<int64_t>(1000000, value));
     else if (!strcmp(name, "coll_timeout_ms")) c->coll_timeout_ms = (int)std::max<int64_t>(1, std::min<int64_t>(3600000, value));
+    else if (!strcmp(name, "scan_fuse")) c->scan_fuse = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else if (!strcmp(name, "force_exact")) c->force_exact = value != 0;
     else if (!strcmp(name, "inject_fault")) c->inject_fault = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else return fail(LBH_E_INVALID, "unknown option %s", name);
@@ -1760,7 +1764,7 @@ int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, i
             HIP_TRY(lbh_launch_search_fast(dv, half ? ix->emb16 : nullptr, sl->ws, nullptr, sl->qarg, page, has_since, since_ms, tag_mask,
                                            (half && !has_since && !tag_mask) ? lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu, true) : grid,
                                            c->n_cu, c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, timing ? sl->ev[0] : nullptr,
-                                           timing ? sl->ev[1] : nullptr, &xc));
+                                           timing ? sl->ev[1] : nullptr, &xc, c->scan_fuse));
             lbh_cursor cur;
             memset(&cur, 0, sizeof cur);
             HIP_TRY(lbh_launch_search_exact(dv, sl->ws, nullptr, sl->qarg, page, has_since, since_ms, tag_mask, cur, std::min(grid, 512), seq, s,

@@ -105,7 +105,7 @@ void lbh_set_scan_split(const uint32_t w[4]);  // tuning override (env LBH_SCAN_
 // result block written by the final kernels (device) and copied to pinned host memory
 struct lbh_result {
     int32_t count;
-    int32_t overflow;         // fp32 path could not bound its candidate set -> caller re-runs exactly
+    int32_t overflow;         // 1: fp32 path could not bound its candidate set -> caller re-runs exactly; 2: exact path, duplicate keys
     int32_t candidates;       // rows that were re-scored in fp64
     int32_t seq;              // completion ticket: written last, after a system-scope fence (see publish_result)
     float max_err;            // largest |scan score - exact fp64 score| among the re-scored rows (0 on the exact path)
@@ -140,7 +140,8 @@ struct lbh_workspace {
     uint64_t* cand;           // flat, LBH_MAX_BLOCKS x LBH_LIST_CAP entries (ord32<<32 | row)   fast path
     uint64_t* xcand_ord;      // flat, LBH_MAX_BLOCKS*4 x LBH_MAX_PAGE entries: ord64(score)     exact path
     uint32_t* xcand_row;      // same shape: row
-    int32_t* flags;           // 128 ints: [0] overflow, [1] entries in cand, [2] entries in xcand, [64..127] the scan blocks' shared cuts (zeroed by the select kernels)
+    int32_t* flags;           // 128 ints: [0] overflow, [1] entries in cand, [2] entries in xcand, [6..7] 64-bit ticket word of a fused scan (blocks finished; bit 63: unbounded candidate set), [64..127] the scan blocks' shared cuts (zeroed by the select step)
+    uint32_t* bmax;           // LBH_MAX_BLOCKS: entries each scan block left in its region of `cand` (fused select: the last block reads them)
     // batched (K3) workspace, allocated on first use
     double* bq_qmat;          // 256 x 64 fp64 query matrix
     uint64_t* bq_cand;        // 256 x LBH_BQ_PERQ flat candidate lists, one per query
@@ -184,7 +185,7 @@ int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu, bool half = false
 hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, const double* qptr,
                                   const lbh_qarg& qa, int k, int has_since,
                                   int64_t since_ms, uint64_t tag_mask, int grid, int n_cu, int nt, int seq, float margin,
-                                  hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const lbh_xchg* xc = nullptr);
+                                  hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const lbh_xchg* xc = nullptr, int fuse = 1);
 hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
                                    const lbh_qarg& qa, int k, int has_since,
                                    int64_t since_ms, uint64_t tag_mask, const lbh_cursor& cur, int grid, int seq,

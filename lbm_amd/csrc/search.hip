@@ -219,14 +219,25 @@ __host__ __device__ inline int64_t split_start(const lbh_split& sp, int b, int g
     return (int64_t)(((uint64_t)n_tiles * split_cum(sp, b)) / split_cum(sp, grid));  // < 2^26 tiles x < 2^27 weight: fits
 }
 
-template <bool SINCE, bool TAGS, bool NT, bool HALF>
+// the select step (K4 body, defined below) as run by the scan's last block: LBH_SCAN_THREADS threads wide
+__device__ void fused_select(const lbh_dev_index& ix, const double* qs, int k, const uint64_t* cand, int E, lbh_result* res,
+                             float margin, const lbh_xchg& xc);
+__device__ __forceinline__ void publish_result(lbh_result* res, int seq);
+constexpr int LBH_FLAG_TICKET = 6;  // flags[6..7]: 64-bit ticket word of a fused scan -- low half = blocks done, bit 63 = candidate set unbounded
+constexpr unsigned long long LBH_TICKET_OVERFLOW = 1ull << 63;
+
+template <bool SINCE, bool TAGS, bool NT, bool HALF, bool FUSE>
 __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_index ix, const uint16_t* __restrict__ emb16,
                                                                      const double* __restrict__ qptr, lbh_qarg qa,
                                                                      int k, float margin, int64_t since_ms, uint64_t tag_mask,
                                                                      uint64_t* __restrict__ cand,
-                                                                     int32_t* __restrict__ flags, lbh_split sp) {
-    __shared__ uint64_t wbuf[LBH_SCAN_WAVES][LBH_WCAP];
-    __shared__ uint64_t mbuf[LBH_SCAN_WAVES * LBH_WCAP];
+                                                                     int32_t* __restrict__ flags, lbh_split sp,
+                                                                     lbh_result* __restrict__ res, int seq, lbh_xchg xc,
+                                                                     uint32_t* __restrict__ bcnt) {
+    constexpr bool fuse = FUSE;  // the scan's last block also runs the select step (see the tail of this kernel)
+    __shared__ __attribute__((aligned(16))) uint64_t lds_all[2 * LBH_SCAN_WAVES * LBH_WCAP];  // the waves' buffers, then the block's merge buffer; the fused select's stage at the end
+    uint64_t (*wbuf)[LBH_WCAP] = reinterpret_cast<uint64_t (*)[LBH_WCAP]>(lds_all);
+    uint64_t* mbuf = lds_all + LBH_SCAN_WAVES * LBH_WCAP;
     __shared__ int wcnt[LBH_SCAN_WAVES];
 
     const int lane = threadIdx.x & 63;
@@ -275,7 +286,10 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
             cnt = kept;
         }
         if (cnt > LBH_WCAP - 64) {  // more near-ties than the buffer holds: let the exact path decide
-            if (lane == 0) atomicOr(&flags[0], 1);
+            if (lane == 0) {
+                if (fuse) atomicOr(reinterpret_cast<unsigned long long*>(&flags[LBH_FLAG_TICKET]), LBH_TICKET_OVERFLOW);
+                else atomicOr(&flags[0], 1);
+            }
             dead = true;
             cnt = 0;
         }
@@ -391,13 +405,14 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
     const int n2 = pow2_at_least(total, 64);
     for (int i = total + threadIdx.x; i < n2; i += LBH_SCAN_THREADS) mbuf[i] = 0;
     __syncthreads();
-    if (total == 0) return;
+    int my_ns = 0;  // entries this block emits (valid in thread 0)
+    if (total > 0) {
     // A block's k-th best score is a lower bound of the corpus's, so (k-th - margin) of ANY block may cut every block's
-    // output.  flags[64..127] are 64 slots of such cuts (ordered images; zeroed by the select kernel): a block stores
+    // output.  flags[64..127] are 64 slots of such cuts (ordered images; zeroed by the select step): a block stores
     // its own cut into slot (block % 64) with a plain device-scope store and applies the largest of the 64 values it then
     // reads.  Nothing here needs to be exact -- a lost or stale slot is merely a looser, still valid cut -- so there is
     // no atomic (one shared word raised by atomicMax made every finishing block queue behind all the others: the 1 M-claim
-    // scan went from 56 to 66 us).  Late blocks emit almost nothing, and the select kernel sorts a few hundred entries
+    // scan went from 56 to 66 us).  Late blocks emit almost nothing, and the select step sorts a few hundred entries
     // instead of radix-selecting among #blocks x k.
     unsigned int* gslot = reinterpret_cast<unsigned int*>(&flags[64]);
     // The slots are read FIRST (the load is in flight while the merged list is sorted) and the block's own cut is stored
@@ -417,56 +432,220 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
     auto publish_cut = [&](uint32_t own) {
         if (lane == 0) __hip_atomic_store(&gslot[blockIdx.x & 63], own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+    // Where the survivors go.  Two-kernel flavour: appended to ONE flat array (one atomicAdd per block for the position).
+    // Fused flavour: into the block's OWN region of the array, LBH_LIST_CAP entries apart -- no atomic, no round trip
+    // before the stores can go out -- written through to memory (device-coherent stores), because the block that reads
+    // them runs on another XCD, whose L2 is not coherent with this one's.
+    // (entry-major: entry j of block b sits at cand[j * LBH_MAX_BLOCKS + b], so that the last block's loads -- one lane
+    // per block -- are coalesced; a block's own 8-12 stores go to one line each either way)
+    uint64_t* region = cand + blockIdx.x;
 #ifndef LBH_SCAN_WAVE_EPI
 #define LBH_SCAN_WAVE_EPI 1
 #endif
     if (LBH_SCAN_WAVE_EPI && total <= 128) {
         // the usual case (each wave kept ~k rows): one wave sorts the merged list, no more block barriers
-        if (wave != 0) return;
-        wave_sort_desc_dispatch(mbuf, total, n2, lane);
-        uint32_t own = 0;
-        if (total >= k) own = lbh_ord32(lbh_unord32((uint32_t)(mbuf[k - 1] >> 32)) - margin);
-        const uint32_t bthr = shared_cut(own);
-        int ns = 0;  // survivors are a prefix of the sorted list
-        for (int i = lane; i < n2; i += 64) ns += __popcll(__ballot(i < total && (uint32_t)(mbuf[i] >> 32) >= bthr));
-        K2_STAMP(4);
-        int base = 0;
-        if (lane == 0 && ns > 0) base = atomicAdd(&flags[1], ns);
-        base = __shfl(base, 0);
-        for (int i = lane; i < ns; i += 64) cand[base + i] = mbuf[i];
-        if (total >= k) publish_cut(own);
-        K2_STAMP(5);
+        if (wave == 0) {
+            wave_sort_desc_dispatch(mbuf, total, n2, lane);
+            uint32_t own = 0;
+            if (total >= k) own = lbh_ord32(lbh_unord32((uint32_t)(mbuf[k - 1] >> 32)) - margin);
+            const uint32_t bthr = shared_cut(own);
+            int ns = 0;  // survivors are a prefix of the sorted list
+            for (int i = lane; i < n2; i += 64) ns += __popcll(__ballot(i < total && (uint32_t)(mbuf[i] >> 32) >= bthr));
+            K2_STAMP(4);
+            if (fuse) {
+                for (int i = lane; i < ns; i += 64) __hip_atomic_store(&region[(size_t)i * LBH_MAX_BLOCKS], mbuf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                int base = 0;
+                if (lane == 0 && ns > 0) base = atomicAdd(&flags[1], ns);
+                base = __shfl(base, 0);
+                for (int i = lane; i < ns; i += 64) cand[base + i] = mbuf[i];
+            }
+            my_ns = ns;
+            if (total >= k) publish_cut(own);
+            K2_STAMP(5);
+        }
+    } else {
+        sort_desc_u64(mbuf, n2, threadIdx.x, LBH_SCAN_THREADS, BlockSync());
+        uint32_t bthr = 0;
+        if (total >= k) bthr = lbh_ord32(lbh_unord32((uint32_t)(mbuf[k - 1] >> 32)) - margin);
+        const uint32_t own_cut = bthr;
+        // survivors are a prefix of the sorted array
+        __shared__ int nsurv, gbase;
+        __shared__ uint32_t sh_bthr;
+        if (wave == 0) {
+            const uint32_t cut = shared_cut(bthr);
+            if (lane == 0) { nsurv = 0; sh_bthr = cut; }
+        }
+        __syncthreads();
+        bthr = sh_bthr;  // one value for the whole block
+        for (int i = threadIdx.x; i < total; i += LBH_SCAN_THREADS) {
+            const bool in = (uint32_t)(mbuf[i] >> 32) >= bthr;
+            const bool next_in = (i + 1 < total) && (uint32_t)(mbuf[i + 1] >> 32) >= bthr;
+            if (in && !next_in) nsurv = i + 1;
+        }
+        __syncthreads();
+        int ns = nsurv;
+        if (ns > LBH_LIST_CAP) {
+            if (threadIdx.x == 0) {
+                if (fuse) atomicOr(reinterpret_cast<unsigned long long*>(&flags[LBH_FLAG_TICKET]), LBH_TICKET_OVERFLOW);
+                else atomicOr(&flags[0], 1);
+            }
+            ns = LBH_LIST_CAP;
+        }
+        if (fuse) {
+            for (int i = threadIdx.x; i < ns; i += LBH_SCAN_THREADS) __hip_atomic_store(&region[(size_t)i * LBH_MAX_BLOCKS], mbuf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (threadIdx.x == 0) gbase = atomicAdd(&flags[1], ns);
+            __syncthreads();
+            const int base = gbase;
+            for (int i = threadIdx.x; i < ns; i += LBH_SCAN_THREADS) cand[base + i] = mbuf[i];
+        }
+        my_ns = ns;
+        if (wave == 0 && total >= k) publish_cut(own_cut);
+    }
+    }
+    if (!fuse) return;
+    // ---- fused select: the block that finishes LAST cuts the candidate lists and re-ranks, in this very launch.  No
+    // select kernel follows a fused scan: its launch hand-off (4-6 us on the latency path of every query) is gone.
+    // Every block writes its entry count next to its entries, waits until its stores are acknowledged, then takes a
+    // ticket; the holder of the last ticket goes on.  No fence anywhere: an agent-scope release would write back the whole
+    // L2 of this XCD (measured: +25 us at 1 M claims, +75 us at 10 M); the entries were stored write-through instead and
+    // are read with device-coherent loads.  Each of those is a ~2 us round trip to the memory side, so the tail is built
+    // to need as few DEPENDENT ones as possible: acknowledgements -> ticket (its return value carries the overflow flag)
+    // -> ONE round of loads (every block's count and the head of its list, the cut slots).
+    __shared__ int sh_last, sh_stage, sh_over;
+    __shared__ uint32_t sh_precut, sh_precut2;
+    unsigned long long* tw = reinterpret_cast<unsigned long long*>(&flags[LBH_FLAG_TICKET]);
+    if (threadIdx.x == 0) __hip_atomic_store(&bcnt[blockIdx.x], (uint32_t)my_ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): expcnt / lgkmcnt fields left at their maxima
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __syncthreads();
+    const int G = (int)gridDim.x;
+    if (threadIdx.x == 0) {
+        const unsigned long long old = atomicAdd(tw, 1ull);
+        sh_last = (int)(old & 0xFFFFFFFFull) == G - 1;
+        sh_over = (old & LBH_TICKET_OVERFLOW) != 0;
+        sh_precut2 = 0;
+        sh_stage = 0;
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    K4_STAMP(0);
+    const bool overflowed = sh_over;
+    // One round of loads: thread t takes block t -- its count and the first H entries of its list (sorted descending, so
+    // entry 0 is the block's best score); grids beyond one block per thread are handled in further rounds below.
+    constexpr int H = 8;
+    uint32_t c0 = 0;
+    uint64_t h[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) h[j] = 0;
+    if ((int)threadIdx.x < G) {
+        c0 = __hip_atomic_load(&bcnt[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < H; ++j)
+            h[j] = __hip_atomic_load(&cand[(size_t)j * LBH_MAX_BLOCKS + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint32_t gcut = 0;
+    if (wave == 0) gcut = __hip_atomic_load(reinterpret_cast<unsigned int*>(&flags[64]) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t* bm = reinterpret_cast<uint32_t*>(lds_all);  // every block's best score (0: it emitted nothing)
+    for (int b = threadIdx.x + LBH_SCAN_THREADS; b < G; b += LBH_SCAN_THREADS) {
+        const uint32_t cb = __hip_atomic_load(&bcnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t e0 = __hip_atomic_load(&cand[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bm[b] = cb ? (uint32_t)(e0 >> 32) : 0u;
+    }
+#ifdef LBH_K2_TIMING
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    K4_STAMP(11);  // the round of loads is back
+#endif
+    if ((int)threadIdx.x < G) bm[threadIdx.x] = c0 ? (uint32_t)(h[0] >> 32) : 0u;
+    const int G16 = (G + 15) & ~15;  // padded with zeros to whole 16-value batches (a zero is never "above" a real score)
+    for (int b = G + threadIdx.x; b < G16; b += LBH_SCAN_THREADS) bm[b] = 0u;
+    // Two cuts, both lower bounds of (corpus k-th best - margin), applied while the lists are staged in LDS:
+    //  (1) the largest block cut in the slots (every block has published by now);
+    //  (2) the k-th largest of the blocks' BEST scores: those are k different rows, so the corpus's k-th best is at least
+    //      that -- a bound only a few ranks below it, where a block's own k-th best sits hundreds of ranks down
+    //      (1 M claims, top-8: ~1 300 entries in the lists, ~700 reach (1), ~10 reach (2); top-64: 16 000 -> ~80).
+    // The true top-k rows pass every such cut, so whatever else is dropped cannot change the result.
+    if (wave == 0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t t = (uint32_t)__shfl_xor((int)gcut, o);
+            gcut = t > gcut ? t : gcut;
+        }
+        if (lane == 0) sh_precut = gcut;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < G; b += LBH_SCAN_THREADS) {
+        const uint32_t mine = bm[b];
+        if (mine == 0) continue;
+        // is this block's best score the k-th largest of all blocks' bests?  (fewer than k above it, at least k at or above
+        // it; ties may make several threads store the same value.)  16 values per step, four 16-byte LDS broadcasts in flight.
+        int above = 0, at_or_above = 0;
+        const uint4* bm4 = reinterpret_cast<const uint4*>(bm);
+#pragma unroll 2
+        for (int j16 = 0; j16 < G16; j16 += 16) {
+            uint4 o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = bm4[(j16 >> 2) + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                above += (int)(o[u].x > mine) + (int)(o[u].y > mine) + (int)(o[u].z > mine) + (int)(o[u].w > mine);
+                at_or_above += (int)(o[u].x >= mine) + (int)(o[u].y >= mine) + (int)(o[u].z >= mine) + (int)(o[u].w >= mine);
+            }
+        }
+        if (above < k && at_or_above >= k) sh_precut2 = lbh_ord32(lbh_unord32(mine) - margin);
+    }
+    __syncthreads();  // bm (lds_all) is rewritten by the stage below
+    K4_STAMP(12);  // cuts known
+    constexpr int STAGE_CAP = 2 * LBH_SCAN_WAVES * LBH_WCAP;
+    if (!overflowed) {
+        const uint32_t precut = sh_precut > sh_precut2 ? sh_precut : sh_precut2;
+        auto push = [&](uint64_t v) {
+            const int pos = atomicAdd(&sh_stage, 1);
+            if (pos < STAGE_CAP) lds_all[pos] = v;
+        };
+#pragma unroll
+        for (int j = 0; j < H; ++j)
+            if (j < (int)c0 && (uint32_t)(h[j] >> 32) >= precut) push(h[j]);
+        // the rest of a list whose head passed whole, and the lists of the blocks beyond the first round (rare both)
+        for (int b = threadIdx.x; b < G; b += LBH_SCAN_THREADS) {
+            int j0 = 0;
+            uint32_t cb = c0;
+            if (b == (int)threadIdx.x) {
+                if ((int)c0 <= H || (uint32_t)(h[H - 1] >> 32) < precut) continue;
+                j0 = H;
+            } else {
+                cb = __hip_atomic_load(&bcnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (int j = j0; j < (int)cb; ++j) {
+                const uint64_t v = __hip_atomic_load(&cand[(size_t)j * LBH_MAX_BLOCKS + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(v >> 32) < precut) break;  // sorted descending: nothing further down passes
+                push(v);
+            }
+        }
+    }
+    __syncthreads();
+    K4_STAMP(1);
+#ifdef LBH_K2_TIMING
+    if (threadIdx.x == 0) { lbh_k4_dbg[8] = G; lbh_k4_dbg[10] = sh_stage; }
+#endif
+    // the ticket word and the shared cuts start the next launch at zero
+    if (threadIdx.x == 0) __hip_atomic_store(tw, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x >= 64 && threadIdx.x < 128) flags[threadIdx.x] = 0;
+    if (overflowed || sh_stage > STAGE_CAP) {
+        // mass near-ties: more rows within the margin of the k-th best than the buffers hold -- the exact path decides
+        if (threadIdx.x == 0) { res->count = 0; res->overflow = 1; res->candidates = 0; }
+        publish_result(res, seq);
         return;
     }
-    sort_desc_u64(mbuf, n2, threadIdx.x, LBH_SCAN_THREADS, BlockSync());
-    uint32_t bthr = 0;
-    if (total >= k) bthr = lbh_ord32(lbh_unord32((uint32_t)(mbuf[k - 1] >> 32)) - margin);
-    const uint32_t own_cut = bthr;
-    // survivors are a prefix of the sorted array; they go to one flat candidate array in HBM
-    __shared__ int nsurv, gbase;
-    __shared__ uint32_t sh_bthr;
-    if (wave == 0) {
-        const uint32_t cut = shared_cut(bthr);
-        if (lane == 0) { nsurv = 0; sh_bthr = cut; }
-    }
+    __shared__ double fq[64];
+    if (threadIdx.x < 64) fq[threadIdx.x] = qd[threadIdx.x];
     __syncthreads();
-    bthr = sh_bthr;  // one value for the whole block
-    for (int i = threadIdx.x; i < total; i += LBH_SCAN_THREADS) {
-        const bool in = (uint32_t)(mbuf[i] >> 32) >= bthr;
-        const bool next_in = (i + 1 < total) && (uint32_t)(mbuf[i + 1] >> 32) >= bthr;
-        if (in && !next_in) nsurv = i + 1;
-    }
-    __syncthreads();
-    int ns = nsurv;
-    if (ns > LBH_LIST_CAP) {
-        if (threadIdx.x == 0) atomicOr(&flags[0], 1);
-        ns = LBH_LIST_CAP;
-    }
-    if (threadIdx.x == 0) gbase = atomicAdd(&flags[1], ns);
-    __syncthreads();
-    const int base = gbase;
-    for (int i = threadIdx.x; i < ns; i += LBH_SCAN_THREADS) cand[base + i] = mbuf[i];
-    if (wave == 0 && total >= k) publish_cut(own_cut);
+    fused_select(ix, fq, k, lds_all, sh_stage, res, margin, xc);
+    K4_STAMP(6);
+    publish_result(res, seq);
+    K4_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -480,12 +659,12 @@ constexpr int LBH_SEL_REGS = 24;    // ... and up to 24 x 1024 entries the score
 
 // Core: `each(body)` calls body(v) for every value of the calling thread that is in play (the values may sit in global
 // memory, in LDS or in registers).
-template <class Each>
+template <int NT = SEL_THREADS, class Each>
 __device__ uint64_t block_radix_select_each(int nbytes, int64_t krem, Each each, int* hist, int64_t* sh_krem, int* sh_bin) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // value range first: digits are taken from (v - lo), so clustered values (scores share their high
     // bits) spread over the bins instead of serialising every LDS atomic on one bin
-    __shared__ uint64_t sh_lo[SEL_THREADS / 64], sh_hi[SEL_THREADS / 64];
+    __shared__ uint64_t sh_lo[NT / 64], sh_hi[NT / 64];
     uint64_t lo = ~0ull, hi = 0;
     each([&](uint64_t v) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; });
 #pragma unroll
@@ -496,7 +675,7 @@ __device__ uint64_t block_radix_select_each(int nbytes, int64_t krem, Each each,
     }
     if (lane == 0) { sh_lo[wave] = lo; sh_hi[wave] = hi; }
     __syncthreads();
-    for (int w = 0; w < SEL_THREADS / 64; ++w) {
+    for (int w = 0; w < NT / 64; ++w) {
         lo = sh_lo[w] < lo ? sh_lo[w] : lo;
         hi = sh_hi[w] > hi ? sh_hi[w] : hi;
     }
@@ -505,7 +684,7 @@ __device__ uint64_t block_radix_select_each(int nbytes, int64_t krem, Each each,
     nbytes = range ? (64 - __clzll(range) + 7) / 8 : 1;
     uint64_t prefix = 0, pmask = 0;
     for (int b = nbytes - 1; b >= 0; --b) {
-        for (int t = tid; t < 256; t += SEL_THREADS) hist[t] = 0;
+        for (int t = tid; t < 256; t += NT) hist[t] = 0;
         __syncthreads();
         each([&](uint64_t v) {
             if (((v - lo) & pmask) == prefix) atomicAdd(&hist[(int)(((v - lo) >> (8 * b)) & 255)], 1);
@@ -542,44 +721,49 @@ __device__ uint64_t block_radix_select_each(int nbytes, int64_t krem, Each each,
 }
 
 // The same over E indexed entries: val(e, &v) says whether entry e is in play and yields its value.
-template <class F>
+template <int NT = SEL_THREADS, class F>
 __device__ uint64_t block_radix_select(int E, int nbytes, int64_t krem, F val, int* hist, int64_t* sh_krem,
                                        int* sh_bin) {
     auto each = [&](auto body) {
-        for (int e = threadIdx.x; e < E; e += SEL_THREADS) {
+        for (int e = threadIdx.x; e < E; e += NT) {
             uint64_t v;
             if (val(e, &v)) body(v);
         }
     };
-    return block_radix_select_each(nbytes, krem, each, hist, sh_krem, sh_bin);
+    return block_radix_select_each<NT>(nbytes, krem, each, hist, sh_krem, sh_bin);
 }
 
 // shared tail of both final kernels: rows xr[0..M) (+ ord64 scores xo when have_scores) -> exact
 // scores -> exact sort -> result block
+template <int NT = SEL_THREADS>
 __device__ void rerank_and_emit(uint64_t* xo, uint32_t* xr, int M, int k, const lbh_dev_index& ix,
                                 const double* qs, lbh_result* __restrict__ res, bool have_scores, const lbh_xchg& xc,
-                                uint32_t scan_ord0 = 0, uint32_t scan_ord1 = 0) {
+                                const uint32_t* scan_ord = nullptr) {  // scan_ord[i]: fp32 score image of row tid + i * NT
     const int tid = threadIdx.x;
     const int n2 = pow2_at_least(M, 2);
     __shared__ uint32_t sh_err;  // largest |scan score - exact score| among the re-scored rows (float bits, >= 0)
     if (tid == 0) sh_err = 0;
     __syncthreads();
     if (!have_scores) {
-        for (int j = tid; j < M; j += SEL_THREADS) {
-            const double exact = exact_dot_latency(qs, ix.emb64 + (size_t)xr[j] * 64);
-            xo[j] = lbh_ord64(exact);
-            const float err = (float)__builtin_fabs((double)lbh_unord32(j == tid ? scan_ord0 : scan_ord1) - exact);
-            atomicMax(&sh_err, __builtin_bit_cast(uint32_t, err));
+#pragma unroll
+        for (int i = 0; i < (LBH_MCAP + NT - 1) / NT; ++i) {
+            const int j = tid + i * NT;
+            if (j < M) {
+                const double exact = exact_dot_latency(qs, ix.emb64 + (size_t)xr[j] * 64);
+                xo[j] = lbh_ord64(exact);
+                const float err = (float)__builtin_fabs((double)lbh_unord32(scan_ord[i]) - exact);
+                atomicMax(&sh_err, __builtin_bit_cast(uint32_t, err));
+            }
         }
     }
-    for (int j = M + tid; j < n2; j += SEL_THREADS) { xo[j] = 0; xr[j] = PAD_ROW; }
+    for (int j = M + tid; j < n2; j += NT) { xo[j] = 0; xr[j] = PAD_ROW; }
     __syncthreads();
     K4_STAMP(3);  // exact scores
     if (n2 <= 128) {  // the usual case (M ~ k): one wave sorts without block barriers
         if (tid < 64) sort_exact(xo, xr, n2, tid, 64, ix.keys, WaveSync());
         __syncthreads();
     } else {
-        sort_exact(xo, xr, n2, tid, SEL_THREADS, ix.keys, BlockSync());
+        sort_exact(xo, xr, n2, tid, NT, ix.keys, BlockSync());
     }
     K4_STAMP(4);  // sorted
     const int cnt = M < k ? M : k;
@@ -605,7 +789,8 @@ __device__ void rerank_and_emit(uint64_t* xo, uint32_t* xr, int M, int k, const 
 
 // K4 body: global fp32 threshold over E flat candidates, candidate cut, exact fp64 re-rank.
 // `qs` (64 doubles in LDS) must be filled and a barrier passed before the call.
-__device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int k, const uint64_t* __restrict__ cand,
+template <int NT = SEL_THREADS>
+__device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int k, const uint64_t* cand,
                                  int E, lbh_result* __restrict__ res, float margin, const lbh_xchg& xc = lbh_xchg{nullptr, 0, 0}) {
     __shared__ uint64_t sbuf[2 * LBH_MCAP];      // 32 KB: entries, later (ord64 | rows)
     __shared__ int hist[256];
@@ -616,39 +801,58 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
     __syncthreads();
     int M = 0;
     uint32_t thr = 0;
-    if (E <= LBH_RANK_ALL) {
+    constexpr int RANK_ALL = NT >= 1024 ? LBH_RANK_ALL : 2 * NT;  // a narrower block counts ranks for two entries per thread
+    constexpr int RPT = (RANK_ALL + NT - 1) / NT;
+    if (E <= RANK_ALL) {
         // A short list (the scan blocks share their cuts, so this is the usual case): no sort at all.  Thread t counts the
         // entries above entry t (entries are unique: the row sits in the low word; every thread reads the same LDS word at
         // the same time, a broadcast) -- the one with k - 1 above it is the k-th best.  Four barriers instead of the
         // bitonic sort's 36-45.
         __shared__ uint32_t sh_thr;
-        uint64_t v = 0;
-        if (tid < E) v = cand[tid];
-        if (tid < E) sbuf[tid] = v;
+        uint64_t v[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int e = tid + r * NT;
+            v[r] = e < E ? cand[e] : 0ull;
+            if (e < E) sbuf[e] = v[r];
+        }
         if (tid == 0) sh_thr = 0;
         __syncthreads();
-        if (E >= k && tid < E) {
-            int above = 0;
-            for (int i = 0; i < E; ++i) above += sbuf[i] > v;
-            if (above == k - 1) sh_thr = lbh_ord32(lbh_unord32((uint32_t)(v >> 32)) - margin);
+        if (E >= k) {
+            int above[RPT];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) above[r] = 0;
+            for (int i = 0; i < E; ++i) {
+                const uint64_t o = sbuf[i];
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) above[r] += o > v[r];
+            }
+#pragma unroll
+            for (int r = 0; r < RPT; ++r)
+                if (tid + r * NT < E && above[r] == k - 1) sh_thr = lbh_ord32(lbh_unord32((uint32_t)(v[r] >> 32)) - margin);
         }
         __syncthreads();
         thr = sh_thr;
-        const bool keep = tid < E && (uint32_t)(v >> 32) >= thr;
-        int pos = 0;
-        if (keep) pos = atomicAdd(&sh_cnt, 1);
+        int pos[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const bool keep = tid + r * NT < E && (uint32_t)(v[r] >> 32) >= thr;
+            pos[r] = keep ? atomicAdd(&sh_cnt, 1) : -1;
+        }
         __syncthreads();  // every entry is in a register before the survivors are packed into sbuf
-        if (keep) sbuf[pos] = v;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r)
+            if (pos[r] >= 0) sbuf[pos[r]] = v[r];
         __syncthreads();
         M = sh_cnt;
-    } else if (E <= LBH_SORT_ALL) {  // few entries: sort them all; more: radix-select the k-th score first (a 4096-entry sort took 20+ us)
-        for (int e = tid; e < E; e += SEL_THREADS) sbuf[e] = cand[e];
+    } else if (NT >= SEL_THREADS && E <= LBH_SORT_ALL) {  // few entries: sort them all; more: radix-select the k-th score first (a 4096-entry sort took 20+ us)
+        for (int e = tid; e < E; e += NT) sbuf[e] = cand[e];
         const int n2 = pow2_at_least(E, 2);
-        for (int i = E + tid; i < n2; i += SEL_THREADS) sbuf[i] = 0;
+        for (int i = E + tid; i < n2; i += NT) sbuf[i] = 0;
         __syncthreads();
-        sort_desc_u64(sbuf, n2, tid, SEL_THREADS, BlockSync());
+        sort_desc_u64(sbuf, n2, tid, NT, BlockSync());
         if (E >= k) thr = lbh_ord32(lbh_unord32((uint32_t)(sbuf[k - 1] >> 32)) - margin);
-        for (int i = tid; i < E; i += SEL_THREADS) {
+        for (int i = tid; i < E; i += NT) {
             const bool in = (uint32_t)(sbuf[i] >> 32) >= thr;
             const bool next_in = (i + 1 < E) && (uint32_t)(sbuf[i + 1] >> 32) >= thr;
             if (in && !next_in) sh_cnt = i + 1;
@@ -661,30 +865,30 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
         // path's 6.9 for 1 200-2 000 entries -- dropped.)
         // the usual single-query case (512 blocks x k candidates): ONE pass over the global list into LDS; the
         // min/max pass, the digit passes and the cut then read LDS (each global pass cost 1-2 us of L2 latency)
-        for (int e = tid; e < E; e += SEL_THREADS) sbuf[e] = cand[e];
+        for (int e = tid; e < E; e += NT) sbuf[e] = cand[e];
         __syncthreads();
         if (E >= k) {
             auto val = [&](int e, uint64_t* v) {
                 *v = sbuf[e] >> 32;
                 return true;
             };
-            const uint32_t kth = (uint32_t)block_radix_select(E, 4, k, val, hist, &sh_krem, &sh_bin);
+            const uint32_t kth = (uint32_t)block_radix_select<NT>(E, 4, k, val, hist, &sh_krem, &sh_bin);
             thr = lbh_ord32(lbh_unord32(kth) - margin);
         }
-        uint64_t mine[2 * LBH_MCAP / SEL_THREADS];  // read everything before the survivors are packed into sbuf
+        uint64_t mine[2 * LBH_MCAP / NT];  // read everything before the survivors are packed into sbuf
 #pragma unroll
-        for (int i = 0; i < 2 * LBH_MCAP / SEL_THREADS; ++i) {
-            const int e = tid + i * SEL_THREADS;
+        for (int i = 0; i < 2 * LBH_MCAP / NT; ++i) {
+            const int e = tid + i * NT;
             mine[i] = e < E ? sbuf[e] : 0ull;
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 2 * LBH_MCAP / SEL_THREADS; ++i) {
-            if (tid + i * SEL_THREADS < E && (uint32_t)(mine[i] >> 32) >= thr) sbuf[atomicAdd(&sh_cnt, 1)] = mine[i];
+        for (int i = 0; i < 2 * LBH_MCAP / NT; ++i) {
+            if (tid + i * NT < E && (uint32_t)(mine[i] >> 32) >= thr) sbuf[atomicAdd(&sh_cnt, 1)] = mine[i];
         }
         __syncthreads();
         M = sh_cnt;
-    } else if (E <= LBH_SEL_REGS * SEL_THREADS) {
+    } else if (NT == SEL_THREADS && E <= LBH_SEL_REGS * SEL_THREADS) {
         // A long list (top_k 64: ~16 000-23 000 entries from 256-512 blocks; beyond 24 576 the path below): every thread takes the scores of its
         // entries into REGISTERS with one batch of independent loads; the min/max pass, the digit passes and the cut then
         // run without touching global memory (five passes over the global list cost 25 of this kernel's 41 us).
@@ -719,10 +923,10 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
                 *v = cand[e] >> 32;
                 return true;
             };
-            const uint32_t kth = (uint32_t)block_radix_select(E, 4, k, val, hist, &sh_krem, &sh_bin);
+            const uint32_t kth = (uint32_t)block_radix_select<NT>(E, 4, k, val, hist, &sh_krem, &sh_bin);
             thr = lbh_ord32(lbh_unord32(kth) - margin);
         }
-        for (int e = tid; e < E; e += SEL_THREADS) {
+        for (int e = tid; e < E; e += NT) {
             const uint64_t v = cand[e];
             if ((uint32_t)(v >> 32) >= thr) {
                 const int pos = atomicAdd(&sh_cnt, 1);
@@ -741,18 +945,27 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
         return;
     }
     // rows out of sbuf into registers, then re-use sbuf as (ord64[MCAP], rows[MCAP])
-    uint32_t myrows[2], myord[2];
-    myrows[0] = tid < M ? (uint32_t)sbuf[tid] : PAD_ROW;
-    myrows[1] = tid + SEL_THREADS < M ? (uint32_t)sbuf[tid + SEL_THREADS] : PAD_ROW;
-    myord[0] = tid < M ? (uint32_t)(sbuf[tid] >> 32) : 0u;
-    myord[1] = tid + SEL_THREADS < M ? (uint32_t)(sbuf[tid + SEL_THREADS] >> 32) : 0u;
+    constexpr int MPT = (LBH_MCAP + NT - 1) / NT;
+    uint32_t myrows[MPT], myord[MPT];
+#pragma unroll
+    for (int i = 0; i < MPT; ++i) {
+        const int j = tid + i * NT;
+        myrows[i] = j < M ? (uint32_t)sbuf[j] : PAD_ROW;
+        myord[i] = j < M ? (uint32_t)(sbuf[j] >> 32) : 0u;
+    }
     __syncthreads();
     uint64_t* xo = sbuf;
     uint32_t* xr = reinterpret_cast<uint32_t*>(sbuf + LBH_MCAP);
-    if (tid < M) xr[tid] = myrows[0];
-    if (tid + SEL_THREADS < M) xr[tid + SEL_THREADS] = myrows[1];
+#pragma unroll
+    for (int i = 0; i < MPT; ++i)
+        if (tid + i * NT < M) xr[tid + i * NT] = myrows[i];
     __syncthreads();
-    rerank_and_emit(xo, xr, M, k, ix, qs, res, false, xc, myord[0], myord[1]);
+    rerank_and_emit<NT>(xo, xr, M, k, ix, qs, res, false, xc, myord);
+}
+
+__device__ void fused_select(const lbh_dev_index& ix, const double* qs, int k, const uint64_t* cand, int E, lbh_result* res,
+                             float margin, const lbh_xchg& xc) {
+    select_fast_body<LBH_SCAN_THREADS>(ix, qs, k, cand, E, res, margin, xc);  // `cand`: the staged list in LDS
 }
 
 // Completion ticket: the result block lives in device-mapped pinned host memory, so once every writer
@@ -2269,34 +2482,44 @@ lbh_split lbh_scan_split(int64_t n_rows, int grid, int n_cu) {
 hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, const double* qptr,
                                   const lbh_qarg& qa, int k, int has_since,
                                   int64_t since_ms, uint64_t tag_mask, int grid, int n_cu, int nt, int seq, float margin,
-                                  hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const lbh_xchg* xc) {
+                                  hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const lbh_xchg* xc, int fuse) {
     hipError_t e;
+    // fuse: 0 never, 1 when the grid is one block per CU (small and medium corpora, where the hand-off between two
+    // launches is a visible share of the query), 2 always
+    fuse = (fuse >= 2 || (fuse == 1 && grid <= n_cu)) && !xc && ws.bmax;
     // the fp16 flavour keeps the grid-stride loop: contiguous ranges cost it 2-3 % (10 M rows: 195 -> 198-201 us)
     const lbh_split sp = emb16 ? lbh_split{{0, 0, 0, 0}, 0} : lbh_scan_split(ix.n, grid, n_cu);
     if (ev0) (void)hipEventRecord(ev0, s);
     const dim3 g(grid), b(LBH_SCAN_THREADS);
-#define LBH_SCAN_ARGS ix, emb16, qptr, qa, k, margin, since_ms, tag_mask, ws.cand, ws.flags, sp
-#define LBH_SCAN_DISPATCH(NTV, HV)                                                                           \
-    do {                                                                                                     \
-        if (has_since && tag_mask) scan_f32_kernel<true, true, NTV, HV><<<g, b, 0, s>>>(LBH_SCAN_ARGS);      \
-        else if (has_since) scan_f32_kernel<true, false, NTV, HV><<<g, b, 0, s>>>(LBH_SCAN_ARGS);            \
-        else if (tag_mask) scan_f32_kernel<false, true, NTV, HV><<<g, b, 0, s>>>(LBH_SCAN_ARGS);             \
-        else scan_f32_kernel<false, false, NTV, HV><<<g, b, 0, s>>>(LBH_SCAN_ARGS);                          \
+    const lbh_xchg xcv = xc ? *xc : lbh_xchg{nullptr, 0, 0};
+#define LBH_SCAN_ARGS ix, emb16, qptr, qa, k, margin, since_ms, tag_mask, ws.cand, ws.flags, sp, ws.result_dev, seq, xcv, ws.bmax
+#define LBH_SCAN_DISPATCH(NTV, HV, FV)                                                                           \
+    do {                                                                                                         \
+        if (has_since && tag_mask) scan_f32_kernel<true, true, NTV, HV, FV><<<g, b, 0, s>>>(LBH_SCAN_ARGS);      \
+        else if (has_since) scan_f32_kernel<true, false, NTV, HV, FV><<<g, b, 0, s>>>(LBH_SCAN_ARGS);            \
+        else if (tag_mask) scan_f32_kernel<false, true, NTV, HV, FV><<<g, b, 0, s>>>(LBH_SCAN_ARGS);             \
+        else scan_f32_kernel<false, false, NTV, HV, FV><<<g, b, 0, s>>>(LBH_SCAN_ARGS);                          \
+    } while (0)
+#define LBH_SCAN_DISPATCH2(NTV, HV)          \
+    do {                                     \
+        if (fuse) LBH_SCAN_DISPATCH(NTV, HV, true); \
+        else LBH_SCAN_DISPATCH(NTV, HV, false);     \
     } while (0)
     if (emb16) {
-        if (nt) LBH_SCAN_DISPATCH(true, true);
-        else LBH_SCAN_DISPATCH(false, true);
+        if (nt) LBH_SCAN_DISPATCH2(true, true);
+        else LBH_SCAN_DISPATCH2(false, true);
     } else {
-        if (nt) LBH_SCAN_DISPATCH(true, false);
-        else LBH_SCAN_DISPATCH(false, false);
+        if (nt) LBH_SCAN_DISPATCH2(true, false);
+        else LBH_SCAN_DISPATCH2(false, false);
     }
+#undef LBH_SCAN_DISPATCH2
 #undef LBH_SCAN_DISPATCH
 #undef LBH_SCAN_ARGS
     if (ev1) (void)hipEventRecord(ev1, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, qptr, qa, k, ws.cand, ws.flags, ws.result_dev, seq, margin,
-                                                 xc ? *xc : lbh_xchg{nullptr, 0, 0});
+    if (fuse) return hipSuccess;  // the scan's last block publishes the result
+    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, qptr, qa, k, ws.cand, ws.flags, ws.result_dev, seq, margin, xcv);
     return hipGetLastError();
 }
 
@@ -2393,17 +2616,18 @@ hipError_t lbh_launch_search_noalloc(void* scratch_ptr, const lbh_dev_index& ix,
     if (grid > NA_FAST_BLOCKS) grid = NA_FAST_BLOCKS;
     const dim3 g(grid), b(LBH_SCAN_THREADS);
     const lbh_split sp = lbh_scan_split(ix.n, grid, n_cu);
-#define LBH_NA_ARGS ix, nullptr, nullptr, qa, k, margin, since_ms, tag_mask, cand, flags, sp
+#define LBH_NA_ARGS ix, nullptr, nullptr, qa, k, margin, since_ms, tag_mask, cand, flags, sp, res, 1, lbh_xchg{nullptr, 0, 0}, nullptr
+    // not fused: the sequence is stream-ordered with no host step in between, there is nothing to gain
     if (nt) {
-        if (has_since && tag_mask) scan_f32_kernel<true, true, true, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
-        else if (has_since) scan_f32_kernel<true, false, true, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
-        else if (tag_mask) scan_f32_kernel<false, true, true, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
-        else scan_f32_kernel<false, false, true, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
+        if (has_since && tag_mask) scan_f32_kernel<true, true, true, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
+        else if (has_since) scan_f32_kernel<true, false, true, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
+        else if (tag_mask) scan_f32_kernel<false, true, true, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
+        else scan_f32_kernel<false, false, true, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
     } else {
-        if (has_since && tag_mask) scan_f32_kernel<true, true, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
-        else if (has_since) scan_f32_kernel<true, false, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
-        else if (tag_mask) scan_f32_kernel<false, true, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
-        else scan_f32_kernel<false, false, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
+        if (has_since && tag_mask) scan_f32_kernel<true, true, false, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
+        else if (has_since) scan_f32_kernel<true, false, false, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
+        else if (tag_mask) scan_f32_kernel<false, true, false, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
+        else scan_f32_kernel<false, false, false, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
     }
 #undef LBH_NA_ARGS
     select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, nullptr, qa, k, cand, flags, res, 1, margin, lbh_xchg{nullptr, 0, 0});

@@ -66,4 +66,6 @@ if hasattr(lib, "lbh_debug_k4_times"):
     print("  select kernel (medians of 8): last scan block written %.2f, select starts %.2f us after the scan's start;" % (m[0], m[1]))
     print("    then +us: counters read %.2f, candidates cut %.2f, exact scores %.2f, sorted %.2f, result written %.2f, published %.2f"
           % tuple(m[2:]))
-    print("    candidates in the flat list E = %d, kept for the exact re-rank M = %d (last search)" % (k4[8], k4[9]))
+    if k4[11]:
+        print("    fused tail, after the ticket: loads back +%.2f us, cuts known +%.2f us" % ((k4[11] - k4[0]) / 100.0, (k4[12] - k4[0]) / 100.0))
+    print("    candidates in the flat list E = %d, kept for the exact re-rank M = %d (last search); staged by a fused scan's last block after its pre-cut: %d" % (k4[8], k4[9], k4[10]))
