@@ -64,6 +64,11 @@ struct lbh_ctx {
                          // 2 = one fp16 product (a third of the matrix work, margin 2.2e-3)
     int spin_us = 5000;  // poll the completion ticket this long before blocking in hipStreamSynchronize (0 = always block)
     int coll_timeout_ms = 60000;  // claim-sharded searches: longest wait for the all-gather (a peer that never arrives) before the call fails
+    // K1's token memo (embed.hip): token -> its two SHA-256 digests, kept for the life of the context
+    int memo_log2 = 20;            // option "k1_memo_log2": 2^n entries of 128 B (default 2^20 = 128 MiB; 0 = off); allocated at the first large batch
+    uint64_t* memo_table = nullptr;
+    uint32_t memo_mask = 0;
+    uint32_t memo_epoch = 0;       // launches that used the table so far (a launch trusts only entries of earlier ones)
     int scan_fuse = 1;     // option "scan_fuse": the scan's last block runs the select step itself -- 0 never, 1 = when the grid is one block per CU (default), 2 always
     int force_exact = 0;   // option "force_exact" (diagnostic / parity tests): single-query searches skip the fp32 scan and rank with the exact fp64 scan
     int inject_fault = 0;  // TEST HOOK (option "inject_fault", one-shot): 1 = this rank's local search of the next sharded call fails;
@@ -157,6 +162,39 @@ int ensure_ctx_scratch(lbh_ctx* c, int64_t text_bytes, int64_t n_off, int64_t n_
         c->d_vec_cap = cap;
     }
     return LBH_OK;
+}
+
+// The memo argument of the next K1 launch on the context's stream (callers hold c->mu or the index's exclusive lock:
+// launches that use the table are stream-ordered one behind the other).  Small batches -- a query's text, a single
+// publish -- go without it: they could overlap a bulk launch on another stream, and have nothing to gain.
+constexpr int64_t LBH_MEMO_MIN_BATCH = 2048;
+lbh_memo next_memo(lbh_ctx* c, int64_t n) {
+    lbh_memo none{nullptr, 0, 0};
+    if (c->memo_log2 <= 0 || n < LBH_MEMO_MIN_BATCH) return none;
+    if (!c->memo_table) {
+        const int lg = std::max(8, std::min(24, c->memo_log2));
+        const size_t bytes = ((size_t)1 << lg) * 128;
+        uint64_t* t = nullptr;
+        if (hipMalloc((void**)&t, bytes) != hipSuccess) {  // no room: vectorise without it
+            (void)hipGetLastError();
+            c->memo_log2 = 0;
+            return none;
+        }
+        if (hipMemsetAsync(t, 0, bytes, c->stream) != hipSuccess) {
+            (void)hipFree(t);
+            c->memo_log2 = 0;
+            return none;
+        }
+        c->memo_table = t;
+        c->memo_mask = (uint32_t)(((size_t)1 << lg) - 1);
+        c->memo_epoch = 0;
+    }
+    if (c->memo_epoch >= (1u << 24) - 2) {  // the tag's epoch field is about to wrap: start over with an empty table
+        if (hipMemsetAsync(c->memo_table, 0, ((size_t)c->memo_mask + 1) * 128, c->stream) != hipSuccess) return none;
+        c->memo_epoch = 0;
+    }
+    c->memo_epoch += 1;
+    return lbh_memo{c->memo_table, c->memo_mask, c->memo_epoch};
 }
 
 template <class T>
@@ -732,6 +770,7 @@ int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx) {
     }
     if (const char* e4 = getenv("LBH_BQ_MODE")) c->bq_mode = std::max(0, std::min(2, atoi(e4)));
     if (const char* e3 = getenv("LBH_SPIN_US")) c->spin_us = std::max(0, std::min(1000000, atoi(e3)));
+    if (const char* e9 = getenv("LBH_K1_MEMO_LOG2")) c->memo_log2 = atoi(e9) <= 0 ? 0 : std::max(8, std::min(24, atoi(e9)));
     if (const char* e8 = getenv("LBH_SCAN_FUSE")) c->scan_fuse = std::max(0, std::min(2, atoi(e8)));
     if (const char* e7 = getenv("LBH_COLL_TIMEOUT_MS")) c->coll_timeout_ms = std::max(1, std::min(3600000, atoi(e7)));
     hipError_t e0 = hipSetDevice(c->device);
@@ -757,6 +796,7 @@ int lbh_shutdown(lbh_ctx* c) {
     if (c->d_text) (void)hipFree(c->d_text);
     if (c->d_off) (void)hipFree(c->d_off);
     if (c->d_vec) (void)hipFree(c->d_vec);
+    if (c->memo_table) (void)hipFree(c->memo_table);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto& ev : c->copy_ev)
@@ -780,6 +820,16 @@ int lbh_set_option(lbh_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "bq_mode")) c->bq_mode = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else if (!strcmp(name, "spin_us")) c->spin_us = (int)std::max<int64_t>(0, std::min<int64_t>(1000000, value));
     else if (!strcmp(name, "coll_timeout_ms")) c->coll_timeout_ms = (int)std::max<int64_t>(1, std::min<int64_t>(3600000, value));
+    else if (!strcmp(name, "k1_memo_log2")) {
+        const int lg = value <= 0 ? 0 : (int)std::max<int64_t>(8, std::min<int64_t>(24, value));
+        if (c->memo_table && lg != c->memo_log2) {  // a new size (or off): drop the table once the stream is idle
+            (void)hipSetDevice(c->device);
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipFree(c->memo_table);
+            c->memo_table = nullptr;
+        }
+        c->memo_log2 = lg;
+    }
     else if (!strcmp(name, "scan_fuse")) c->scan_fuse = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else if (!strcmp(name, "force_exact")) c->force_exact = value != 0;
     else if (!strcmp(name, "inject_fault")) c->inject_fault = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
@@ -828,7 +878,8 @@ int lbh_embed_batch_dim(lbh_ctx* c, const uint8_t* utf8, const int64_t* offsets,
     }
     if (bytes > 0) HIP_TRY(hipMemcpyAsync(c->d_text, utf8 + base, (size_t)bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_off, offp, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(lbh_launch_embed(c->d_text, c->d_off, n, c->d_vec, nullptr, s, dim));
+    const lbh_memo memo = next_memo(c, n);
+    HIP_TRY(lbh_launch_embed(c->d_text, c->d_off, n, c->d_vec, nullptr, s, dim, &memo));
     HIP_TRY(hipMemcpyAsync(out_f64, c->d_vec, (size_t)n * 64 * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return LBH_OK;
@@ -839,7 +890,12 @@ int lbh_embed_batch_dev(lbh_ctx* c, const uint8_t* utf8_dev, const int64_t* offs
     if (!c || n < 0 || total_bytes < 0 || (n > 0 && (!offsets_dev || !out_f64_dev))) return fail(LBH_E_INVALID, "bad argument");
     if (n == 0) return LBH_OK;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(lbh_launch_embed(utf8_dev, offsets_dev, n, out_f64_dev, out_f32_dev, c->stream));
+    lbh_memo memo;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        memo = next_memo(c, n);
+    }
+    HIP_TRY(lbh_launch_embed(utf8_dev, offsets_dev, n, out_f64_dev, out_f32_dev, c->stream, LBH_DIM, &memo));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LBH_OK;
 }
@@ -1002,7 +1058,8 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
             HIP_TRY(hipMemcpyAsync(c->d_off + a, offp + a, (size_t)(b2 - a + 1) * 8, hipMemcpyHostToDevice, c->copy_stream));
             HIP_TRY(hipEventRecord(c->copy_ev[sl], c->copy_stream));
             HIP_TRY(hipStreamWaitEvent(s, c->copy_ev[sl], 0));
-            HIP_TRY(lbh_launch_embed(c->d_text, c->d_off + a, b2 - a, ix->emb64 + (r0 + a) * 64, ix->emb32 + (r0 + a) * 64, s));
+            const lbh_memo memo = next_memo(c, b2 - a);  // (text_lk holds c->mu)
+            HIP_TRY(lbh_launch_embed(c->d_text, c->d_off + a, b2 - a, ix->emb64 + (r0 + a) * 64, ix->emb32 + (r0 + a) * 64, s, LBH_DIM, &memo));
             if (sl == n_sl - 1) {
                 rc = copy_metadata(c->copy_stream);
                 if (rc) return rc;

@@ -96,12 +96,16 @@ __device__ unsigned long long lbh_k1_dbg[8];
 // (lb/latent.py:50-52 is order-sensitive per claim; claims do not interact).  Token positions are relative to their
 // own claim's text.
 constexpr int EMB_GROUP = 4;
-constexpr int EMB_HEAD = 128;  // bytes of every claim fetched up front (one round of independent loads per group)
+#ifndef LBH_EMB_HEAD
+#define LBH_EMB_HEAD 256
+#endif
+constexpr int EMB_HEAD = LBH_EMB_HEAD;  // bytes of every claim fetched up front (one round of independent loads per group); tokens inside it
+                                        // take the word-wise message assembly and the memo (128 covered 44 % of the bench corpus's hash batches)
 
 __global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __restrict__ utf8,
                                                                 const int64_t* __restrict__ offsets, int64_t n,
                                                                 double* __restrict__ out64,
-                                                                float* __restrict__ out32, int dim) {
+                                                                float* __restrict__ out32, int dim, lbh_memo memo) {
     __shared__ double lut[256];
     __shared__ int tok_start[EMB_WAVES][TOK_RING];
     __shared__ int tok_end[EMB_WAVES][TOK_RING];
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __
     lut[threadIdx.x & 255] = ((double)(threadIdx.x & 255) / 127.5) - 1.0;
     __syncthreads();
 #ifdef LBH_K1_TIMING
-    unsigned long long k1_t[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long k1_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int* ts = tok_start[wave];
@@ -180,6 +184,7 @@ __global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) { const int o2 = __shfl_xor(nw, off); nw = o2 > nw ? o2 : nw; }
                 nw = __builtin_amdgcn_readfirstlane(nw);
+                uint32_t f1 = 0x811C9DC5u ^ (uint32_t)tl, f2 = 0x9E3779B9u + (uint32_t)tl;  // two 32-bit hashes of the lowered token (memo)
 #pragma unroll
                 for (int i = 0; i < 14; ++i) {
                     uint32_t x = 0;
@@ -195,6 +200,11 @@ __global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __
                         const uint32_t ge_A = (x & 0x7F7F7F7Fu) + 0x3F3F3F3Fu;
                         const uint32_t gt_Z = (x & 0x7F7F7F7Fu) + 0x25252525u;
                         x += ((ge_A & ~gt_Z & ~x) & 0x80808080u) >> 2;
+                        if (memo.table && nv > 0) {  // words that hold token bytes only (the loop runs to the WAVE's longest message); the same in both lanes of a token
+                            f1 = (f1 ^ x) * 16777619u;
+                            f2 = (f2 + x) * 0x85EBCA6Bu;
+                            f2 = (f2 << 13) | (f2 >> 19);
+                        }
                         const int mk = total - 4 * i;                     // position of the 0x80 mark relative to this word
                         if (mk >= 0 && mk < 4) x |= 0x80u << (8 * mk);
                         x = __builtin_bswap32(x);                         // message words are big-endian
@@ -203,7 +213,99 @@ __global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __
                 }
                 w[14] = 0u;
                 w[15] = (uint32_t)total * 8u;
-                if (act) sha256_compress(st, w);
+                // ---- token memo (lb/latent.py:47-49 is a pure function of the lower-cased token): a table in HBM, kept for
+                // the life of the context, maps a token to its 64 digest bytes.  Entry = 128 B: tag (launch epoch << 40 |
+                // 40-bit fingerprint; 0 = empty), the 56 bytes of the token's padded one-block message (the exact key),
+                // the two digests.  Buckets of four slots, filled front to back and never emptied, so a lookup stops at
+                // the first empty slot.  An entry counts only when it was written by an EARLIER launch (tag epoch < this
+                // launch's): it was complete before this kernel started, whichever XCD wrote it.  Entries of the running
+                // launch are neither read (they may be half written, and another XCD's L2 may hold stale lines of them) nor
+                // written twice (the tag is taken with an atomic compare-and-swap).  The saving comes when EVERY token of
+                // a batch is found: the wave then copies 32 bytes per lane instead of running the compression.
+                int hit = -1, vacant = -1;
+                uint64_t fp = 0;
+                uint32_t bucket = 0;
+                bool all_hit = false;
+                if (memo.table) {
+                    fp = (((uint64_t)(f2 & 0xFFu)) << 32) | f1;
+                    fp += fp == 0;
+                    bucket = (f2 >> 8) & memo.mask & ~3u;
+                    // Two rounds of independent loads (the wave is latency-bound here: two waves per SIMD, and the table
+                    // is larger than an XCD's L2): (1) the bucket's four tags; (2) key and digest half of the slot whose
+                    // fingerprint matches -- used only if the key then compares equal.
+                    uint4 d0 = {0u, 0u, 0u, 0u}, d1 = {0u, 0u, 0u, 0u};
+                    if (act) {
+                        const uint64_t* e0 = memo.table + (size_t)bucket * 16;
+                        uint64_t tg[4];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) tg[jj] = e0[jj * 16];
+                        int cand = -1;
+#pragma unroll
+                        for (int jj = 3; jj >= 0; --jj) {  // back to front: the first empty slot and the first match win
+                            if (tg[jj] == 0) { vacant = jj; cand = -1; }
+                            else if ((tg[jj] & 0xFFFFFFFFFFull) == fp) {
+                                if ((uint32_t)(tg[jj] >> 40) < memo.epoch) cand = jj;
+                                else { vacant = -2; cand = -1; }  // being written by this launch: neither usable nor ours to write
+                            }
+                        }
+                        if (cand >= 0) {
+                            const uint64_t* e = e0 + cand * 16;
+                            const uint2 k0 = *reinterpret_cast<const uint2*>(e + 1);
+                            const uint4 k1 = *reinterpret_cast<const uint4*>(e + 2);
+                            const uint4 k2 = *reinterpret_cast<const uint4*>(e + 4);
+                            const uint4 k3 = *reinterpret_cast<const uint4*>(e + 6);
+                            const uint4* dg = reinterpret_cast<const uint4*>(e + 8) + v * 2;
+                            d0 = dg[0];
+                            d1 = dg[1];
+                            const bool same = k0.x == w[0] && k0.y == w[1] && k1.x == w[2] && k1.y == w[3] && k1.z == w[4] && k1.w == w[5] &&
+                                              k2.x == w[6] && k2.y == w[7] && k2.z == w[8] && k2.w == w[9] && k3.x == w[10] && k3.y == w[11] &&
+                                              k3.z == w[12] && k3.w == w[13];
+                            if (same) hit = cand;  // (lane (t, 1) compares against ITS message, which differs: it takes lane (t, 0)'s verdict below)
+                            else vacant = -2;      // a fingerprint collision: this token is simply not memoised
+                        }
+                    }
+                    hit = __shfl(hit, lane & ~1);  // lane (t, 1) learns what lane (t, 0) found
+                    vacant = __shfl(vacant, lane & ~1);
+                    all_hit = __all(!act || hit >= 0);
+                    if (all_hit && act) {
+                        uint32_t* dst = &dig[wave][t][v * 8];
+                        dst[0] = d0.x; dst[1] = d0.y; dst[2] = d0.z; dst[3] = d0.w;
+                        dst[4] = d1.x; dst[5] = d1.y; dst[6] = d1.z; dst[7] = d1.w;
+                    }
+                }
+                K1_ADD(6, 0, 1);                  // batches on the one-block fast path
+                if (all_hit) K1_ADD(7, 0, 1);     // ... of which every token came from the memo
+                if (!all_hit) {
+                    // a token nobody has entered yet: take its slot and store the key NOW (the compression below turns w[]
+                    // into the message schedule), the digests once both variants are in LDS
+                    unsigned long long* mine = nullptr;
+                    if (memo.table && act && v == 0 && hit < 0 && vacant >= 0) {
+                        unsigned long long* e = reinterpret_cast<unsigned long long*>(memo.table + (size_t)(bucket + vacant) * 16);
+                        // (device-coherent re-check first: a frequent token is seen as missing by thousands of waves of the
+                        // first launch, and that many compare-and-swaps on one address would queue up for milliseconds)
+                        if (__hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull &&
+                            atomicCAS(e, 0ull, ((unsigned long long)memo.epoch << 40) | fp) == 0ull) {
+                            mine = e;
+                            uint32_t* kw = reinterpret_cast<uint32_t*>(e + 1);
+#pragma unroll
+                            for (int i = 0; i < 14; ++i) kw[i] = w[i];
+                        }
+                    }
+                    if (act) sha256_compress(st, w);
+                    if (act) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) dig[wave][t][v * 8 + i] = __builtin_bswap32(st[i]);
+                    }
+                    if (memo.table) {
+                        __builtin_amdgcn_wave_barrier();  // the neighbour lane's digest is in LDS
+                        if (mine) {
+                            uint32_t* dd = reinterpret_cast<uint32_t*>(mine + 8);
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) dd[i] = dig[wave][t][i];
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             } else
             for (int blk = 0; __any(blk < nblk); ++blk) {
                 if (blk < nblk) {
@@ -222,7 +324,7 @@ __global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __
                     sha256_compress(st, w);
                 }
             }
-            if (act) {
+            if (!__all(one_block_in_head) && act) {  // general path: its digests (the fast path stored or copied its own above)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) dig[wave][t][v * 8 + i] = __builtin_bswap32(st[i]);
             }
@@ -309,7 +411,7 @@ __global__ __launch_bounds__(EMB_WAVES * 64) void embed_kernel(const uint8_t* __
     }
 #ifdef LBH_K1_TIMING
     if (lane == 0)
-        for (int i = 0; i < 6; ++i) atomicAdd(&lbh_k1_dbg[i], k1_t[i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(&lbh_k1_dbg[i], k1_t[i]);
 #endif
 }
 
@@ -406,11 +508,12 @@ __global__ void scatter_u64_kernel(uint64_t* dst, const int64_t* __restrict__ ro
 }  // namespace
 
 hipError_t lbh_launch_embed(const uint8_t* utf8_dev, const int64_t* offsets_dev, int64_t n, double* out64_dev,
-                            float* out32_dev, hipStream_t s, int dim) {
+                            float* out32_dev, hipStream_t s, int dim, const lbh_memo* memo) {
     if (n <= 0) return hipSuccess;
     int64_t blocks = (n + EMB_WAVES * EMB_GROUP - 1) / (EMB_WAVES * EMB_GROUP);
     if (blocks > 256 * 32) blocks = 256 * 32;
-    embed_kernel<<<dim3((unsigned)blocks), dim3(EMB_WAVES * 64), 0, s>>>(utf8_dev, offsets_dev, n, out64_dev, out32_dev, dim);
+    embed_kernel<<<dim3((unsigned)blocks), dim3(EMB_WAVES * 64), 0, s>>>(utf8_dev, offsets_dev, n, out64_dev, out32_dev, dim,
+                                                                         memo ? *memo : lbh_memo{nullptr, 0, 0});
     return hipGetLastError();
 }
 

@@ -166,8 +166,16 @@ struct lbh_workspace {
 // ---- kernel launchers (defined in the .hip files) ---------------------------------------------
 // embed.hip
 // dim: LBH_DIM for the index; 1..63 = embed(text, dim) of lb/latent.py:41 (components >= dim are written as 0)
+// K1's token memo (embed.hip): a table of 128-byte entries in HBM that maps a lower-cased token to its 64 digest bytes.
+// `epoch` numbers the launches that use the table (strictly increasing, < 2^24): a launch trusts only entries whose tag
+// carries a smaller epoch.  Launches that use it must not overlap (they run on the context's stream, one after another).
+struct lbh_memo {
+    uint64_t* table;   // (mask + 1) entries x 16 words; NULL = no memo
+    uint32_t mask;     // entries - 1 (a power of two, >= 4)
+    uint32_t epoch;
+};
 hipError_t lbh_launch_embed(const uint8_t* utf8_dev, const int64_t* offsets_dev, int64_t n, double* out64_dev,
-                            float* out32_dev, hipStream_t s, int dim = LBH_DIM);
+                            float* out32_dev, hipStream_t s, int dim = LBH_DIM, const lbh_memo* memo = nullptr);
 hipError_t lbh_launch_cosine(const double* a_dev, const double* b_dev, int64_t n, double* out_dev, hipStream_t s);
 hipError_t lbh_launch_f64_to_f32(const double* in_dev, float* out_dev, int64_t n_elems, hipStream_t s);
 hipError_t lbh_launch_move_row(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,

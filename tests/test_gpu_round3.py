@@ -153,3 +153,42 @@ def test_sharded_graph_batched_recent_snapshot_single_rank(hip, golden_synth):
         assert g.snapshot() == og.snapshot()
     finally:
         comm.close()
+
+
+def test_k1_token_memo_is_exact_cold_warm_and_overfull(hip):
+    """K1's token memo (token -> its two SHA-256 digests, kept in HBM across launches; lb/latent.py:47-49 is a pure
+    function of the lower-cased token) must never change a bit: cold table, warm table, a table far too small for the
+    vocabulary (every bucket full: misses fall back to the compression), tokens that differ only in case (one entry),
+    tokens the memo does not serve (two-block messages, tokens beyond a claim's prefetched head), and the memo switched off."""
+    from lbm_amd import synth
+    rng = np.random.default_rng(5)
+    ch = synth.make_chunk(0, 60_000, seed=77, real_sha_keys=False)
+    texts = [ch.text(i) for i in range(0, 60_000, 12)]
+    alphabet = list("abcdefgXYZ0189_") + [" ", " ", "-", "é"]
+    for i in range(2500):  # a large, flat vocabulary of mixed-case tokens, some longer than one SHA block, some past byte 128
+        n_tok = int(rng.integers(0, 30))
+        toks = ["".join(rng.choice(alphabet, size=int(rng.integers(1, 12)))) for _ in range(n_tok)]
+        if i % 50 == 0:
+            toks.insert(int(rng.integers(0, n_tok + 1)), "L" * int(rng.integers(50, 70)))
+        texts.append(" ".join(toks))
+    texts += ["Hello hello HELLO hElLo", "hello", "", "w00001 W00001"]
+    want = orc.embed_batch(texts)
+    try:
+        for lg in (20, 8, 0):
+            hip.set_option("k1_memo_log2", lg)
+            for rep in range(3):  # launch 1 fills the table, launches 2 and 3 read it
+                got = hip.embed_batch(texts)
+                assert got.tobytes() == want.tobytes(), (lg, rep)
+            # a different batch against the table the first one left behind
+            other = [t.upper() for t in texts[:3000]] + texts[3000:6000]
+            assert hip.embed_batch(other).tobytes() == orc.embed_batch(other).tobytes(), lg
+        # through the index (sliced ingest: several launches per call, each its own epoch)
+        hip.set_option("k1_memo_log2", 20)
+        ix = hip.Index()
+        for _ in range(2):
+            ids = ix.add_texts(ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)
+            pick = rng.choice(ch.n, size=1500, replace=False)
+            assert ix.get_embeddings(ids[pick]).tobytes() == orc.embed_batch([ch.text(int(i)) for i in pick]).tobytes()
+        ix.close()
+    finally:
+        hip.set_option("k1_memo_log2", 20)

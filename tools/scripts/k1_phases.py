@@ -18,3 +18,11 @@ n = int(out[4])
 print(f"claims {n}; hash batches {int(out[5])}; embed_batch incl. copies {1e3 * (t1 - t0):.1f} ms")
 print(f"per claim and wave (us): up to normalisation {out[0] / n / 100:.2f}  of which hashing {out[1] / n / 100:.2f}, accumulation {out[2] / n / 100:.2f}, "
       f"classifier + loads {(int(out[0]) - int(out[1]) - int(out[2])) / n / 100:.2f};  normalise + store {out[3] / n / 100:.2f}")
+print(f"hash batches on the one-block fast path {int(out[6])}, served whole by the token memo {int(out[7])}")
+for rep in range(2):  # the same text again: the memo is warm now
+    lib.lbh_debug_k1_times(None, 1)
+    t0 = time.perf_counter(); _hip.embed_batch_packed(ch.blob, ch.offsets); t1 = time.perf_counter()
+    lib.lbh_debug_k1_times(out.ctypes.data_as(ctypes.c_void_p), 0)
+    n = int(out[4])
+    print(f"again: hash batches {int(out[5])}, fast path {int(out[6])}, from the memo {int(out[7])}; per claim and wave (us): hashing {out[1] / n / 100:.2f}, "
+          f"accumulation {out[2] / n / 100:.2f}, rest {(int(out[0]) - int(out[1]) - int(out[2])) / n / 100:.2f}, normalise + store {out[3] / n / 100:.2f}; call {1e3 * (t1 - t0):.1f} ms")
