@@ -13,12 +13,15 @@ c = collections.defaultdict(list)
 for r in rows:
     if "embed_kernel" in r["Kernel_Name"]:
         c[r["Counter_Name"]].append(float(r["Counter_Value"]))
-med = {k: statistics.median(v) for k, v in c.items()}
+med = {k: statistics.median(v) for k, v in c.items()}  # with the token memo on: launch 1 fills the table (cold), the median launch reads it (warm)
+first = {k: v[0] for k, v in c.items()}
 simds = 256 * 4
 cycles = med["GRBM_GUI_ACTIVE"] / 8  # the counter is summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
 out = {"source": sys.argv[4] if len(sys.argv) > 4 else "",
        "launches": len(c["SQ_INSTS_VALU"]), "claims_per_launch": claims, "ms_per_launch_under_the_profiler": ms,
        "counters_median_per_launch": med,
+       "first_launch_cold_memo": {"valu_wave_instructions_per_claim": first["SQ_INSTS_VALU"] / claims,
+                                  "valu_busy_fraction": first["SQ_ACTIVE_INST_VALU"] * 4 / (simds * first["GRBM_GUI_ACTIVE"] / 8)},
        "embed_kernel": {
            "valu_wave_instructions_per_claim": med["SQ_INSTS_VALU"] / claims,
            "salu_instructions_per_claim": med["SQ_INSTS_SALU"] / claims,
