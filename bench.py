@@ -170,6 +170,11 @@ def vectorise_roofline(k1, claims, t_add, t_add_first, chunk, n_chunks):
         # same pass: share of SIMD-cycles with a vector instruction executing (these integer instructions occupy the pipe
         # for ~4 cycles each, so the pipe is busier than the 2-cycle issue model says)
         out["valu_busy_fraction_pmc"] = ek.get("valu_busy_fraction")
+        cold = json.load(open(pmc[-1])).get("first_launch_cold_memo")
+        if cold:  # the token memo removes work (hash compressions), it does not raise the issue rate: both counts are given
+            out["cold_memo_first_launch"] = cold
+            out["note"] = ("per-claim instruction count and busy fraction are of a launch with the token memo warm (steady "
+                           "state of an ingest stream); cold_memo_first_launch = every token hashed")
         out["instructions_source"] = f"profiles/{os.path.basename(pmc[-1])} (SQ_INSTS_VALU / claims, same corpus); not measured in this run"
         out["achieved"] = per_claim * out["kernel_claims_per_s"]
         out["frac"] = out["achieved"] / VALU_ISSUE_PER_S

@@ -16,6 +16,14 @@ n = int(sys.argv[1])
 opt = sys.argv[2]
 vals = [int(v) for v in sys.argv[3].split(",")]
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 300
+gap_us = float(os.environ.get("LAT_GAP_US", "0"))  # idle time between two calls (a serving loop is not back to back)
+
+
+def idle():
+    if gap_us > 0:
+        t_end = time.perf_counter() + gap_us * 1e-6
+        while time.perf_counter() < t_end:
+            pass
 ix = _hip.Index()
 ix.reserve(n)
 done = ci = 0
@@ -28,7 +36,7 @@ while done < n:
     ci += 1
 queries = synth.make_queries(64, seed=4321)
 qv = _hip.embed_batch(queries)
-out = {"claims": n, "live": ix.size(), "option": opt, "runs": []}
+out = {"claims": n, "live": ix.size(), "option": opt, "gap_us_between_calls": gap_us, "runs": []}
 ref = {}
 for rnd in range(2):  # every setting twice, interleaved: box drift shows up as a spread between the rounds
     for v in vals:
@@ -43,6 +51,7 @@ for rnd in range(2):  # every setting twice, interleaved: box drift shows up as 
                 t0 = time.perf_counter()
                 r = ix.search_shard(qv[i % 64], k, _hip.SINCE_NONE, 0)
                 lat.append(time.perf_counter() - t0)
+                idle()
                 key = (k, i % 64)
                 sig = (r[0].tobytes(), r[1].tobytes())
                 assert ref.setdefault(key, sig) == sig, "results differ between settings"
@@ -51,6 +60,7 @@ for rnd in range(2):  # every setting twice, interleaved: box drift shows up as 
                 t0 = time.perf_counter()
                 ix.search_text(queries[i % 64], k)
                 tl.append(time.perf_counter() - t0)
+                idle()
             st.want_timing = 1
             scan = []
             for i in range(60):

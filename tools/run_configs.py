@@ -121,6 +121,14 @@ def main():
     ix1, _ = build_index(1_000_000)
     out["config2_1M_single_query"] = {"k8": time_single(ix1, qv, 8, _hip.SINCE_NONE, 0),
                                       "k64": time_single(ix1, qv, 64, _hip.SINCE_NONE, 0)}
+    # at this size the scan's last block runs the select step (scan_fuse, grid <= one block per CU), so scan_us above is
+    # the whole fused launch (scan + select); the two-kernel flavour gives the scan alone and the previous p50
+    _hip.set_option("scan_fuse", 0)
+    out["config2_1M_single_query"]["two_kernels_scan_fuse_0"] = {"k8": time_single(ix1, qv, 8, _hip.SINCE_NONE, 0),
+                                                                 "k64": time_single(ix1, qv, 64, _hip.SINCE_NONE, 0)}
+    _hip.set_option("scan_fuse", 1)
+    out["config2_1M_single_query"]["note"] = ("k8/k64: default (fused select; scan_us, scan_GBps and frac_of_8TBps are of the "
+                                              "fused launch, select included); two_kernels_scan_fuse_0: scan_us is the scan kernel alone")
     ix1.close()
 
     # big index: configs 3, 4 (per-GPU leg), 5

@@ -14,6 +14,8 @@ step write;  timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_scan_write
 step k1pmc;  timeout -s KILL 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $O/pmc_k1 -o k1 --output-format csv -- python3 $R/tools/prof_k1.py 1000000 5 > $O/pmc_k1.log 2>&1
 B="python3 $R/tools/bench_batched.py 10000000 256 8 2"
 step k3sq;   timeout -s KILL 150 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/pmc_k3_sq -o sq --output-format csv -- $B > $O/pmc_k3_sq.log 2>&1
+step k3fetch; timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_k3_fetch -o f --output-format csv -- $B > $O/pmc_k3_fetch.log 2>&1
+step k3write; timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_k3_write -o w --output-format csv -- $B > $O/pmc_k3_write.log 2>&1
 step k3trace; timeout -k 10 200 rocprofv3 --kernel-trace -d $O/r03_k3_trace -o k3 --output-format csv -- $B > $O/r03_k3_trace.log 2>&1
 find $O -name '*_agent_info.csv' -delete
 echo profiles done
