@@ -69,6 +69,7 @@ struct lbh_ctx {
     uint64_t* memo_table = nullptr;
     uint32_t memo_mask = 0;
     uint32_t memo_epoch = 0;       // launches that used the table so far (a launch trusts only entries of earlier ones)
+    int scan_xb_k = 24;    // option "scan_xb_k": smallest top_k for which the scan's waves share a cross-block bound at their compactions (0 = never)
     int scan_fuse = 1;     // option "scan_fuse": the scan's last block runs the select step itself -- 0 never, 1 = when the grid is one block per CU (default), 2 always
     int force_exact = 0;   // option "force_exact" (diagnostic / parity tests): single-query searches skip the fp32 scan and rank with the exact fp64 scan
     int inject_fault = 0;  // TEST HOOK (option "inject_fault", one-shot): 1 = this rank's local search of the next sharded call fails;
@@ -276,7 +277,8 @@ int slot_create(lbh_index* ix, int which, lbh_slot** out) {
     HIP_TRY(hipMalloc((void**)&w.xcand_ord, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 8));
     HIP_TRY(hipMalloc((void**)&w.xcand_row, (size_t)LBH_MAX_BLOCKS * LBH_SCAN_WAVES * LBH_MAX_PAGE * 4));
     HIP_TRY(hipMalloc((void**)&w.flags, 512));
-    HIP_TRY(hipMalloc((void**)&w.bmax, (size_t)LBH_MAX_BLOCKS * 4));
+    HIP_TRY(hipMalloc((void**)&w.bmax, (size_t)LBH_MAX_BLOCKS * 4 + (size_t)LBH_XB_SLOTS * 8));
+    HIP_TRY(hipMemset(w.bmax, 0, (size_t)LBH_MAX_BLOCKS * 4 + (size_t)LBH_XB_SLOTS * 8));  // launch numbers start at 1: a zero slot is empty
     HIP_TRY(hipMalloc((void**)&sl->d_off, 16));
     HIP_TRY(hipHostMalloc((void**)&w.result_host, sizeof(lbh_result), hipHostMallocMapped | hipHostMallocCoherent));
     HIP_TRY(hipHostGetDevicePointer((void**)&w.result_dev, w.result_host, 0));
@@ -567,7 +569,7 @@ int run_page(lbh_index* ix, lbh_slot* sl, int page, int64_t since_ms, uint64_t t
         if (half && !emb16_current(ix)) return LBH_NEED_EMB16;
         if (fast)
             HIP_TRY(lbh_launch_search_fast(dv, half ? ix->emb16 : nullptr, sl->ws, sl->qptr, sl->qarg, page, has_since, since_ms,
-                                           tag_mask, (half && !has_since && !tag_mask) ? lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu, true) : grid, c->n_cu, c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, e0, e1, nullptr, c->scan_fuse));
+                                           tag_mask, (half && !has_since && !tag_mask) ? lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu, true) : grid, c->n_cu, c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, e0, e1, nullptr, c->scan_fuse, c->scan_xb_k));
         else {
             const int xgrid = std::min(grid, 512);
             HIP_TRY(lbh_launch_search_exact(dv, sl->ws, sl->qptr, sl->qarg, page, has_since, since_ms, tag_mask, cur, xgrid, seq, s, e0, e1));
@@ -771,6 +773,7 @@ int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx) {
     if (const char* e4 = getenv("LBH_BQ_MODE")) c->bq_mode = std::max(0, std::min(2, atoi(e4)));
     if (const char* e3 = getenv("LBH_SPIN_US")) c->spin_us = std::max(0, std::min(1000000, atoi(e3)));
     if (const char* e9 = getenv("LBH_K1_MEMO_LOG2")) c->memo_log2 = atoi(e9) <= 0 ? 0 : std::max(8, std::min(24, atoi(e9)));
+    if (const char* e9 = getenv("LBH_SCAN_XB_K")) c->scan_xb_k = std::max(0, atoi(e9));
     if (const char* e8 = getenv("LBH_SCAN_FUSE")) c->scan_fuse = std::max(0, std::min(2, atoi(e8)));
     if (const char* e7 = getenv("LBH_COLL_TIMEOUT_MS")) c->coll_timeout_ms = std::max(1, std::min(3600000, atoi(e7)));
     hipError_t e0 = hipSetDevice(c->device);
@@ -830,6 +833,7 @@ int lbh_set_option(lbh_ctx* c, const char* name, int64_t value) {
         }
         c->memo_log2 = lg;
     }
+    else if (!strcmp(name, "scan_xb_k")) c->scan_xb_k = (int)std::max<int64_t>(0, std::min<int64_t>(1 << 20, value));
     else if (!strcmp(name, "scan_fuse")) c->scan_fuse = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else if (!strcmp(name, "force_exact")) c->force_exact = value != 0;
     else if (!strcmp(name, "inject_fault")) c->inject_fault = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
@@ -1821,7 +1825,7 @@ int lbh_index_search_sharded(lbh_index* ix, lbh_comm* cm, const double* q_f64, i
             HIP_TRY(lbh_launch_search_fast(dv, half ? ix->emb16 : nullptr, sl->ws, nullptr, sl->qarg, page, has_since, since_ms, tag_mask,
                                            (half && !has_since && !tag_mask) ? lbh_scan_grid(ix->n, c->n_cu, c->scan_blocks_per_cu, true) : grid,
                                            c->n_cu, c->scan_nt, seq, (half ? LBH_MARGIN_F16 : LBH_MARGIN) * nscale, s, timing ? sl->ev[0] : nullptr,
-                                           timing ? sl->ev[1] : nullptr, &xc, c->scan_fuse));
+                                           timing ? sl->ev[1] : nullptr, &xc, c->scan_fuse, c->scan_xb_k));
             lbh_cursor cur;
             memset(&cur, 0, sizeof cur);
             HIP_TRY(lbh_launch_search_exact(dv, sl->ws, nullptr, sl->qarg, page, has_since, since_ms, tag_mask, cur, std::min(grid, 512), seq, s,

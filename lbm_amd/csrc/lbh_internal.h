@@ -19,6 +19,7 @@
 #define LBH_BQ_QT_STRIDE 32                     // ints between two queries' list counters (one cache line each)
 #define LBH_BQ_KMAX 16                          // largest top_k the batched path serves
 #define LBH_MAX_BLOCKS 2048                     // max scan grid (lists in the workspace)
+#define LBH_XB_SLOTS 512                        // blocks that publish their best score for the cross-block bound (K2, large k)
 
 // fp32 scan vs reference fp64 score: rigorous bound on |s32 - s64| is < 4e-6 for unit 64-vectors
 // (input rounding 2*2^-24 + 64 fp32 roundings, DESIGN.md "Error bound"); candidates are every row
@@ -141,7 +142,8 @@ struct lbh_workspace {
     uint64_t* xcand_ord;      // flat, LBH_MAX_BLOCKS*4 x LBH_MAX_PAGE entries: ord64(score)     exact path
     uint32_t* xcand_row;      // same shape: row
     int32_t* flags;           // 128 ints: [0] overflow, [1] entries in cand, [2] entries in xcand, [6..7] 64-bit ticket word of a fused scan (blocks finished; bit 63: unbounded candidate set), [64..127] the scan blocks' shared cuts (zeroed by the select step)
-    uint32_t* bmax;           // LBH_MAX_BLOCKS: entries each scan block left in its region of `cand` (fused select: the last block reads them)
+    uint32_t* bmax;           // LBH_MAX_BLOCKS: entries each scan block left in its region of `cand` (fused select: the last block reads them);
+                              // then LBH_XB_SLOTS 64-bit words: launch << 32 | best ordered score of a block (cross-block bound)
     // batched (K3) workspace, allocated on first use
     double* bq_qmat;          // 256 x 64 fp64 query matrix
     uint64_t* bq_cand;        // 256 x LBH_BQ_PERQ flat candidate lists, one per query
@@ -193,7 +195,7 @@ int lbh_scan_grid(int64_t n_rows, int n_cu, int blocks_per_cu, bool half = false
 hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, const double* qptr,
                                   const lbh_qarg& qa, int k, int has_since,
                                   int64_t since_ms, uint64_t tag_mask, int grid, int n_cu, int nt, int seq, float margin,
-                                  hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const lbh_xchg* xc = nullptr, int fuse = 1);
+                                  hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const lbh_xchg* xc = nullptr, int fuse = 1, int xb_k = 0);
 hipError_t lbh_launch_search_exact(const lbh_dev_index& ix, const lbh_workspace& ws, const double* qptr,
                                    const lbh_qarg& qa, int k, int has_since,
                                    int64_t since_ms, uint64_t tag_mask, const lbh_cursor& cur, int grid, int seq,

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
                                                                      uint64_t* __restrict__ cand,
                                                                      int32_t* __restrict__ flags, lbh_split sp,
                                                                      lbh_result* __restrict__ res, int seq, lbh_xchg xc,
-                                                                     uint32_t* __restrict__ bcnt) {
+                                                                     uint32_t* __restrict__ bcnt, int xb_k) {
     constexpr bool fuse = FUSE;  // the scan's last block also runs the select step (see the tail of this kernel)
     __shared__ __attribute__((aligned(16))) uint64_t lds_all[2 * LBH_SCAN_WAVES * LBH_WCAP];  // the waves' buffers, then the block's merge buffer; the fused select's stage at the end
     uint64_t (*wbuf)[LBH_WCAP] = reinterpret_cast<uint64_t (*)[LBH_WCAP]>(lds_all);
@@ -271,15 +271,79 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
     int cnt = 0;
     bool dead = false;
 
+    // Cross-block bound for large k.  A wave sees only n / (4 x grid) rows, so its own k-th best is a weak threshold when
+    // k is large (1 M claims, k = 64: the 64th of 977 rows admits 6.5 % of everything that follows, the buffer is sorted
+    // again every ~64 admitted rows, and the blocks hand 16 000+ candidates to the select step).  But every block's BEST
+    // score so far is known early, and the k-th largest of the blocks' bests belongs to k different rows: a lower bound
+    // of the corpus's k-th best that is already sharp after two or three tiles.  At a compaction -- a slow path anyway --
+    // a wave raises its block's slot (bcnt[LBH_MAX_BLOCKS ..]: 64-bit words, launch number << 32 | ordered score, so a
+    // slot left by an earlier launch reads as empty and nothing has to be cleared) and takes the k-th largest of the
+    // slots as its threshold.  Stale or missing slots only loosen the bound.  Nothing is stored or loaded while streaming.
+    __shared__ uint32_t sh_bmax;
+    const bool xb = bcnt != nullptr && xb_k > 0 && k >= xb_k && (int)gridDim.x >= k;
+    unsigned long long* xslot = reinterpret_cast<unsigned long long*>(bcnt + LBH_MAX_BLOCKS);
+    const int xg = (int)gridDim.x < LBH_XB_SLOTS ? (int)gridDim.x : LBH_XB_SLOTS;  // a subset of the blocks is as valid
+    uint32_t omax = 0, wpub = 0;  // this lane's best score so far; the wave's best at its last publication
+    if (xb) {
+        if (threadIdx.x == 0) sh_bmax = 0;
+        __syncthreads();
+        if (2 * k < trigger) trigger = 2 * k < 64 ? 64 : 2 * k;  // the shared bound does not need 4 k rows of this wave
+    }
+    auto xb_publish = [&]() {
+        uint32_t wm = omax;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t t = (uint32_t)__shfl_xor((int)wm, o);
+            wm = t > wm ? t : wm;
+        }
+        if (lane == 0 && wm > wpub) {
+            const uint32_t old = atomicMax(&sh_bmax, wm);
+            if (wm > old && (int)blockIdx.x < LBH_XB_SLOTS)
+                __hip_atomic_store(&xslot[blockIdx.x], ((unsigned long long)(uint32_t)seq << 32) | wm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        wpub = wm;
+    };
+    constexpr int XV = LBH_XB_SLOTS / 64;
+    auto xb_bound = [&]() -> uint32_t {  // largest t (to 2^-24 of the range) such that at least k slots hold a score >= t; 0 = none
+        uint32_t v[XV];
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int b = i * 64 + lane;
+            unsigned long long w = 0;
+            if (b < xg) w = __hip_atomic_load(&xslot[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[i] = (uint32_t)(w >> 32) == (uint32_t)seq ? (uint32_t)w : 0u;
+        }
+        uint32_t lo = 0, hi = 0xFFFFFFFFu;
+        for (int it = 0; it < 24; ++it) {
+            const uint32_t mid = lo + ((hi - lo) >> 1) + ((hi - lo) & 1u);  // > lo
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < XV; ++i) c += __popcll(__ballot(v[i] >= mid));
+            if (c >= k) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    };
+
     // sort the wave buffer, raise the threshold, drop what fell below it
-    auto compact = [&]() {
+    auto compact = [&](bool in_loop) {
         const int n2 = pow2_at_least(cnt, 64);
         __builtin_amdgcn_wave_barrier();
+        const bool ex = xb && in_loop;
+        if (ex) xb_publish();
         wave_sort_desc_dispatch(buf, cnt, n2, lane);  // in registers; slots [cnt, n2) come back as 0
-        if (cnt >= k) {
-            const uint32_t kth = (uint32_t)(buf[k - 1] >> 32);
-            const uint32_t nt = lbh_ord32(lbh_unord32(kth) - margin);
-            if (nt > thr) thr = nt;
+        if (ex) {
+            const uint32_t bound = xb_bound();
+            if (bound) {
+                const uint32_t nt = lbh_ord32(lbh_unord32(bound) - margin);
+                if (nt > thr) thr = nt;
+            }
+        }
+        if (cnt >= k || ex) {
+            if (cnt >= k) {
+                const uint32_t kth = (uint32_t)(buf[k - 1] >> 32);
+                const uint32_t nt = lbh_ord32(lbh_unord32(kth) - margin);
+                if (nt > thr) thr = nt;
+            }
             int kept = 0;
             for (int i = lane; i < n2; i += 64)
                 kept += __popcll(__ballot(i < cnt && (uint32_t)(buf[i] >> 32) >= thr));
@@ -375,6 +439,7 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
         if (TAGS) valid = valid && ((ix.tags[myrow < n ? myrow : 0] & tag_mask) != 0);
 
         const uint32_t o = lbh_ord32(s);
+        omax = (valid && o > omax) ? o : omax;
         const bool pass = valid && o >= thr;
         const uint64_t m = __ballot(pass);
         if (m) {
@@ -382,13 +447,13 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
             cnt += __popcll(m);
             __builtin_amdgcn_wave_barrier();
             if (cnt >= trigger) {
-                compact();
+                compact(true);
                 trigger = cnt + 64 < LBH_WCAP - 64 + 1 ? cnt + 64 : LBH_WCAP - 64 + 1;
             }
         }
     }
     K2_STAMP(1);
-    if (!dead && cnt > 0) compact();
+    if (!dead && cnt > 0) compact(false);
     K2_STAMP(2);
     if (lane == 0) wcnt[wave] = cnt;
     __syncthreads();
@@ -2482,7 +2547,7 @@ lbh_split lbh_scan_split(int64_t n_rows, int grid, int n_cu) {
 hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, const double* qptr,
                                   const lbh_qarg& qa, int k, int has_since,
                                   int64_t since_ms, uint64_t tag_mask, int grid, int n_cu, int nt, int seq, float margin,
-                                  hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const lbh_xchg* xc, int fuse) {
+                                  hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const lbh_xchg* xc, int fuse, int xb_k) {
     hipError_t e;
     // fuse: 0 never, 1 when the grid is one block per CU AND the index is small or medium (up to 4 M rows: there the
     // hand-off between two launches is a visible share of the query; beyond, e.g. the fp16 flavour's one-block grid
@@ -2493,7 +2558,7 @@ hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const uint16_t* emb16
     if (ev0) (void)hipEventRecord(ev0, s);
     const dim3 g(grid), b(LBH_SCAN_THREADS);
     const lbh_xchg xcv = xc ? *xc : lbh_xchg{nullptr, 0, 0};
-#define LBH_SCAN_ARGS ix, emb16, qptr, qa, k, margin, since_ms, tag_mask, ws.cand, ws.flags, sp, ws.result_dev, seq, xcv, ws.bmax
+#define LBH_SCAN_ARGS ix, emb16, qptr, qa, k, margin, since_ms, tag_mask, ws.cand, ws.flags, sp, ws.result_dev, seq, xcv, ws.bmax, xb_k
 #define LBH_SCAN_DISPATCH(NTV, HV, FV)                                                                           \
     do {                                                                                                         \
         if (has_since && tag_mask) scan_f32_kernel<true, true, NTV, HV, FV><<<g, b, 0, s>>>(LBH_SCAN_ARGS);      \
@@ -2617,7 +2682,7 @@ hipError_t lbh_launch_search_noalloc(void* scratch_ptr, const lbh_dev_index& ix,
     if (grid > NA_FAST_BLOCKS) grid = NA_FAST_BLOCKS;
     const dim3 g(grid), b(LBH_SCAN_THREADS);
     const lbh_split sp = lbh_scan_split(ix.n, grid, n_cu);
-#define LBH_NA_ARGS ix, nullptr, nullptr, qa, k, margin, since_ms, tag_mask, cand, flags, sp, res, 1, lbh_xchg{nullptr, 0, 0}, nullptr
+#define LBH_NA_ARGS ix, nullptr, nullptr, qa, k, margin, since_ms, tag_mask, cand, flags, sp, res, 1, lbh_xchg{nullptr, 0, 0}, nullptr, 0
     // not fused: the sequence is stream-ordered with no host step in between, there is nothing to gain
     if (nt) {
         if (has_since && tag_mask) scan_f32_kernel<true, true, true, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);

@@ -192,3 +192,41 @@ def test_k1_token_memo_is_exact_cold_warm_and_overfull(hip):
         ix.close()
     finally:
         hip.set_option("k1_memo_log2", 20)
+
+
+def test_cross_block_bound_for_large_k_is_exact(hip):
+    """K2's cross-block bound (top_k >= scan_xb_k: at a compaction a wave takes the k-th largest of the blocks' best scores
+    as its threshold) must not change a result: against the exact fp64 path and against the kernel with the bound off, on
+    duplicate-heavy corpora of several sizes (grids below and above k blocks), k from the switch-over to the page size,
+    filters that leave few valid rows per block, and -- because the slots live across launches -- queries whose scores
+    are orders of magnitude BELOW the previous launch's (a stale slot taken for a current one would cut every row)."""
+    from lbm_amd import synth
+    st = hip.Stats()
+    try:
+        for n in (3_000, 40_000, 700_000):
+            ch = synth.make_chunk(0, n, seed=23 + n % 7, real_sha_keys=False, dup_frac=0.03)
+            ix = hip.Index()
+            ix.add_texts(ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)
+            qv = hip.embed_batch(synth.make_queries(3, seed=3) + [ch.text(11)])
+            p50, p97 = int(ch.created_ms[n // 2]), int(ch.created_ms[n * 97 // 100])
+            cases = [(64, hip.SINCE_NONE, 0), (24, hip.SINCE_NONE, 0), (33, p97, 0), (64, hip.SINCE_NONE, 1 << 40),
+                     (50, p50, 0b11), (64, p97, 1 << 41)]
+            for qi, scale in ((0, 1.0), (0, 1e-3), (1, 1.0), (2, 40.0), (3, 1e-2), (3, 1.0)):
+                q = qv[qi] * scale
+                for k, since, tm in cases:
+                    got = [a.copy() for a in ix.search_shard(q, k, since, tm, st)]  # (the arrays are reused per k)
+                    if since == hip.SINCE_NONE and tm == 0 and n >= 40_000:
+                        assert st.path == 0, (n, k, st.path)  # the fast path served it
+                    hip.set_option("scan_xb_k", 0)
+                    off = [a.copy() for a in ix.search_shard(q, k, since, tm)]
+                    hip.set_option("scan_xb_k", 24)
+                    hip.set_option("force_exact", 1)
+                    want = [a.copy() for a in ix.search_shard(q, k, since, tm)]
+                    hip.set_option("force_exact", 0)
+                    for other in (off, want):
+                        assert got[0].tolist() == other[0].tolist(), (n, qi, scale, k, since, tm)
+                        assert got[1].tobytes() == other[1].tobytes() and got[2].tobytes() == other[2].tobytes()
+            ix.close()
+    finally:
+        hip.set_option("scan_xb_k", 24)
+        hip.set_option("force_exact", 0)
