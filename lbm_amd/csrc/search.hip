@@ -219,6 +219,42 @@ __host__ __device__ inline int64_t split_start(const lbh_split& sp, int b, int g
     return (int64_t)(((uint64_t)n_tiles * split_cum(sp, b)) / split_cum(sp, grid));  // < 2^26 tiles x < 2^27 weight: fits
 }
 
+// Wave-uniform lower bound of the k-th largest of the 64 x XV values the lanes of a wave hold (0 = an empty slot): the
+// largest t, to within 256 ordered-float steps, such that at least k values are >= t; 0 when fewer than k are set.  Any
+// such t is good for a cut, so the search gallops down from the maximum (the k-th largest of a set of maxima sits a
+// few 2^-10 of it away) and bisects what is left: ~15 probes of XV compares + wave votes instead of a sort.
+template <int XV>
+__device__ __forceinline__ uint32_t wave_kth_bound(const uint32_t (&v)[XV], int k) {
+    auto count = [&](uint32_t t) {
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < XV; ++i) c += __popcll(__ballot(v[i] >= t));
+        return c;
+    };
+    uint32_t hi = 0;
+#pragma unroll
+    for (int i = 0; i < XV; ++i) hi = v[i] > hi ? v[i] : hi;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t t = (uint32_t)__shfl_xor((int)hi, o);
+        hi = t > hi ? t : hi;
+    }
+    if (hi == 0) return 0;
+    if (count(hi) >= k) return hi;
+    uint32_t lo = 0;  // count(lo) >= k holds for lo = 0 by convention ("no bound"); hi: count(hi) < k
+    for (uint32_t step = 1u << 14; step; step <<= 2) {
+        const uint32_t probe = hi > step ? hi - step : 0u;
+        if (probe == 0u) break;
+        if (count(probe) >= k) { lo = probe; break; }
+        hi = probe;
+    }
+    while (hi - lo > 256u) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (count(mid) >= k) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 // the select step (K4 body, defined below) as run by the scan's last block: LBH_SCAN_THREADS threads wide
 __device__ void fused_select(const lbh_dev_index& ix, const double* qs, int k, const uint64_t* cand, int E, lbh_result* res,
                              float margin, const lbh_xchg& xc);
@@ -304,7 +340,7 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
         wpub = wm;
     };
     constexpr int XV = LBH_XB_SLOTS / 64;
-    auto xb_bound = [&]() -> uint32_t {  // largest t (to 2^-24 of the range) such that at least k slots hold a score >= t; 0 = none
+    auto xb_bound = [&]() -> uint32_t {  // a lower bound of the k-th largest slot (wave_kth_bound); 0 = fewer than k slots set
         uint32_t v[XV];
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
@@ -313,15 +349,7 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
             if (b < xg) w = __hip_atomic_load(&xslot[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             v[i] = (uint32_t)(w >> 32) == (uint32_t)seq ? (uint32_t)w : 0u;
         }
-        uint32_t lo = 0, hi = 0xFFFFFFFFu;
-        for (int it = 0; it < 24; ++it) {
-            const uint32_t mid = lo + ((hi - lo) >> 1) + ((hi - lo) & 1u);  // > lo
-            int c = 0;
-#pragma unroll
-            for (int i = 0; i < XV; ++i) c += __popcll(__ballot(v[i] >= mid));
-            if (c >= k) lo = mid; else hi = mid - 1;
-        }
-        return lo;
+        return wave_kth_bound<XV>(v, k);
     };
 
     // sort the wave buffer, raise the threshold, drop what fell below it
@@ -579,7 +607,6 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
     // to need as few DEPENDENT ones as possible: acknowledgements -> ticket (its return value carries the overflow flag)
     // -> ONE round of loads (every block's count and the head of its list, the cut slots).
     __shared__ int sh_last, sh_stage, sh_over;
-    __shared__ uint32_t sh_precut, sh_precut2;
     unsigned long long* tw = reinterpret_cast<unsigned long long*>(&flags[LBH_FLAG_TICKET]);
     if (threadIdx.x == 0) __hip_atomic_store(&bcnt[blockIdx.x], (uint32_t)my_ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
@@ -591,7 +618,6 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
         const unsigned long long old = atomicAdd(tw, 1ull);
         sh_last = (int)(old & 0xFFFFFFFFull) == G - 1;
         sh_over = (old & LBH_TICKET_OVERFLOW) != 0;
-        sh_precut2 = 0;
         sh_stage = 0;
     }
     __syncthreads();
@@ -611,10 +637,13 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
         for (int j = 0; j < H; ++j)
             h[j] = __hip_atomic_load(&cand[(size_t)j * LBH_MAX_BLOCKS + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    uint32_t gcut = 0;
-    if (wave == 0) gcut = __hip_atomic_load(reinterpret_cast<unsigned int*>(&flags[64]) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t* bm = reinterpret_cast<uint32_t*>(lds_all);  // every block's best score (0: it emitted nothing)
-    for (int b = threadIdx.x + LBH_SCAN_THREADS; b < G; b += LBH_SCAN_THREADS) {
+    // the shared cut slots: every wave reads all 64 (one per lane) and reduces them itself -- no LDS hand-over
+    uint32_t gcut = __hip_atomic_load(reinterpret_cast<unsigned int*>(&flags[64]) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every block's best score (0: it emitted nothing); the first LBH_XB_SLOTS blocks serve for the bound (a subset of
+    // the groups gives a valid, slightly lower bound)
+    __shared__ uint32_t bm[LBH_XB_SLOTS];
+    const int GB = G < LBH_XB_SLOTS ? G : LBH_XB_SLOTS;
+    for (int b = threadIdx.x + LBH_SCAN_THREADS; b < GB; b += LBH_SCAN_THREADS) {
         const uint32_t cb = __hip_atomic_load(&bcnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint64_t e0 = __hip_atomic_load(&cand[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bm[b] = cb ? (uint32_t)(e0 >> 32) : 0u;
@@ -623,49 +652,38 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
     __builtin_amdgcn_s_waitcnt(0x0F70);
     K4_STAMP(11);  // the round of loads is back
 #endif
-    if ((int)threadIdx.x < G) bm[threadIdx.x] = c0 ? (uint32_t)(h[0] >> 32) : 0u;
-    const int G16 = (G + 15) & ~15;  // padded with zeros to whole 16-value batches (a zero is never "above" a real score)
-    for (int b = G + threadIdx.x; b < G16; b += LBH_SCAN_THREADS) bm[b] = 0u;
+    if ((int)threadIdx.x < GB) bm[threadIdx.x] = c0 ? (uint32_t)(h[0] >> 32) : 0u;
     // Two cuts, both lower bounds of (corpus k-th best - margin), applied while the lists are staged in LDS:
     //  (1) the largest block cut in the slots (every block has published by now);
     //  (2) the k-th largest of the blocks' BEST scores: those are k different rows, so the corpus's k-th best is at least
     //      that -- a bound only a few ranks below it, where a block's own k-th best sits hundreds of ranks down
     //      (1 M claims, top-8: ~1 300 entries in the lists, ~700 reach (1), ~10 reach (2); top-64: 16 000 -> ~80).
-    // The true top-k rows pass every such cut, so whatever else is dropped cannot change the result.
-    if (wave == 0) {
+    // The true top-k rows pass every such cut, so whatever else is dropped cannot change the result.  Every wave works
+    // both out for itself from the same values (wave_kth_bound: a dozen probes), so one barrier -- bm complete -- is all
+    // the block needs here.
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t t = (uint32_t)__shfl_xor((int)gcut, o);
-            gcut = t > gcut ? t : gcut;
-        }
-        if (lane == 0) sh_precut = gcut;
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t t = (uint32_t)__shfl_xor((int)gcut, o);
+        gcut = t > gcut ? t : gcut;
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < G; b += LBH_SCAN_THREADS) {
-        const uint32_t mine = bm[b];
-        if (mine == 0) continue;
-        // is this block's best score the k-th largest of all blocks' bests?  (fewer than k above it, at least k at or above
-        // it; ties may make several threads store the same value.)  16 values per step, four 16-byte LDS broadcasts in flight.
-        int above = 0, at_or_above = 0;
-        const uint4* bm4 = reinterpret_cast<const uint4*>(bm);
-#pragma unroll 2
-        for (int j16 = 0; j16 < G16; j16 += 16) {
-            uint4 o[4];
+    uint32_t kth_of_maxima;
+    if (GB <= 256) {  // one block per CU: four values per lane, half the work per probe
+        uint32_t bv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) o[u] = bm4[(j16 >> 2) + u];
+        for (int i = 0; i < 4; ++i) bv[i] = (i * 64 + lane) < GB ? bm[i * 64 + lane] : 0u;
+        kth_of_maxima = wave_kth_bound<4>(bv, k);
+    } else {
+        uint32_t bv[LBH_XB_SLOTS / 64];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                above += (int)(o[u].x > mine) + (int)(o[u].y > mine) + (int)(o[u].z > mine) + (int)(o[u].w > mine);
-                at_or_above += (int)(o[u].x >= mine) + (int)(o[u].y >= mine) + (int)(o[u].z >= mine) + (int)(o[u].w >= mine);
-            }
-        }
-        if (above < k && at_or_above >= k) sh_precut2 = lbh_ord32(lbh_unord32(mine) - margin);
+        for (int i = 0; i < LBH_XB_SLOTS / 64; ++i) bv[i] = (i * 64 + lane) < GB ? bm[i * 64 + lane] : 0u;
+        kth_of_maxima = wave_kth_bound<LBH_XB_SLOTS / 64>(bv, k);
     }
-    __syncthreads();  // bm (lds_all) is rewritten by the stage below
+    const uint32_t precut2 = kth_of_maxima ? lbh_ord32(lbh_unord32(kth_of_maxima) - margin) : 0u;
     K4_STAMP(12);  // cuts known
     constexpr int STAGE_CAP = 2 * LBH_SCAN_WAVES * LBH_WCAP;
     if (!overflowed) {
-        const uint32_t precut = sh_precut > sh_precut2 ? sh_precut : sh_precut2;
+        const uint32_t precut = gcut > precut2 ? gcut : precut2;
         auto push = [&](uint64_t v) {
             const int pos = atomicAdd(&sh_stage, 1);
             if (pos < STAGE_CAP) lds_all[pos] = v;
@@ -852,6 +870,108 @@ __device__ void rerank_and_emit(uint64_t* xo, uint32_t* xr, int M, int k, const 
     }
 }
 
+// three-way hash-key comparison: < 0 when key(ra) < key(rb)
+__device__ __forceinline__ int key_cmp3(const uint64_t* __restrict__ keys, uint32_t ra, uint32_t rb) {
+    const uint64_t* a = keys + (size_t)ra * 4;
+    const uint64_t* b = keys + (size_t)rb * 4;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint64_t x = a[w], y = b[w];
+        if (x != y) return x < y ? -1 : 1;
+    }
+    return 0;
+}
+
+// Select step for a SHORT candidate list (E <= 128; `cand` in LDS or global memory): ONE wave, no LDS, no barrier.  Every
+// candidate is re-scored exactly -- a lane takes entries lane and lane + 64, the loads of both rows go out together --
+// so no threshold is needed; a lane then counts the entries that come before its own in the reference's order
+// (score descending, key ascending; row index last, so that even duplicate keys get distinct ranks) from wave-uniform
+// broadcasts, and writes its entry at that rank if the rank is below k.  The fused scan's last block stages 8-80 entries
+// for top-8 .. top-64, so this is its usual path: 3.5 us of barriers, LDS sort and re-packing became ~2.
+// Threads other than the first wave fall through; the caller's publish_result has the barrier.
+__device__ void select_small(const lbh_dev_index& ix, const double* qs, int k, const uint64_t* cand, int E,
+                             lbh_result* __restrict__ res, const lbh_xchg& xc) {
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    uint64_t sc[2] = {0, 0};
+    uint32_t row[2] = {PAD_ROW, PAD_ROW}, so[2] = {0, 0};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int e = lane + 64 * r;
+        if (e < E) {
+            const uint64_t v = cand[e];
+            row[r] = (uint32_t)v;
+            so[r] = (uint32_t)(v >> 32);
+        }
+    }
+    uint64_t kw[2][4];  // the rows' hash keys: needed last (result block, ties), requested first
+    {   // one load per cache line of both rows and their keys go out together: everything costs ONE HBM round trip
+        const uint32_t s0 = row[0] == PAD_ROW ? 0u : row[0], s1 = row[1] == PAD_ROW ? 0u : row[1];
+        const double* r0 = ix.emb64 + (size_t)s0 * 64;
+        const double* r1 = ix.emb64 + (size_t)s1 * 64;
+        const double a0 = r0[0], a1 = r0[16], a2 = r0[32], a3 = r0[48], b0 = r1[0], b1 = r1[16], b2 = r1[32], b3 = r1[48];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { kw[0][w] = ix.keys[(size_t)s0 * 4 + w]; kw[1][w] = ix.keys[(size_t)s1 * 4 + w]; }
+        asm volatile("" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+    }
+    float err = 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (row[r] != PAD_ROW) {
+            const double exact = exact_dot(qs, ix.emb64 + (size_t)row[r] * 64);
+            sc[r] = lbh_ord64(exact);
+            const float d = (float)__builtin_fabs((double)lbh_unord32(so[r]) - exact);
+            err = d > err ? d : err;
+        }
+    }
+    int rank[2] = {0, 0};
+    for (int j = 0; j < E; ++j) {  // wave-uniform: entry j is broadcast from the lane and register that hold it
+        const int jl = j & 63;
+        const uint64_t src_s = j < 64 ? sc[0] : sc[1];
+        const uint32_t src_r = j < 64 ? row[0] : row[1];
+        // (v_readlane with a uniform lane number: a few cycles each; ds_bpermute would make this loop 3 LDS round trips long)
+        const uint64_t sj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(src_s >> 32), jl) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)src_s, jl);
+        const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)src_r, jl);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (row[r] == PAD_ROW || rj == row[r]) continue;
+            if (sj > sc[r]) ++rank[r];
+            else if (sj == sc[r]) {
+                const int c = key_cmp3(ix.keys, rj, row[r]);
+                if (c < 0 || (c == 0 && rj < row[r])) ++rank[r];
+            }
+        }
+    }
+    const int cnt = E < k ? E : k;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (row[r] != PAD_ROW && rank[r] < cnt) {
+            const int t = rank[r];
+            res->rows[t] = row[r];
+            res->scores[t] = lbh_unord64(sc[r]);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) res->keys[t][w] = kw[r][w];
+            if (xc.dst) {
+                int64_t* e = xc.dst + 6 * (t + 1);
+                e[0] = (int64_t)__builtin_bit_cast(uint64_t, lbh_unord64(sc[r]));
+                e[1] = (int64_t)((ix.ids ? ix.ids[row[r]] : (uint64_t)row[r]) * xc.gid_mul + xc.gid_add);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) e[2 + w] = (int64_t)kw[r][w];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(err, o);
+        err = t > err ? t : err;
+    }
+    if (lane == 0) {
+        res->count = cnt; res->overflow = 0; res->candidates = E; res->max_err = err;
+        if (xc.dst) xc.dst[0] = cnt;
+    }
+}
+
 // K4 body: global fp32 threshold over E flat candidates, candidate cut, exact fp64 re-rank.
 // `qs` (64 doubles in LDS) must be filled and a barrier passed before the call.
 template <int NT = SEL_THREADS>
@@ -862,6 +982,10 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
     __shared__ int64_t sh_krem;
     __shared__ int sh_bin, sh_cnt;
     const int tid = threadIdx.x;
+    if (E <= 64) {  // block-uniform (one entry per lane; with two, 65-128 entries took longer than the block-wide path below)
+        select_small(ix, qs, k, cand, E, res, xc);
+        return;
+    }
     if (tid == 0) sh_cnt = 0;
     __syncthreads();
     int M = 0;
