@@ -219,12 +219,28 @@ __host__ __device__ inline int64_t split_start(const lbh_split& sp, int b, int g
     return (int64_t)(((uint64_t)n_tiles * split_cum(sp, b)) / split_cum(sp, grid));  // < 2^26 tiles x < 2^27 weight: fits
 }
 
-// Wave-uniform lower bound of the k-th largest of the 64 x XV values the lanes of a wave hold (0 = an empty slot): the
-// largest t, to within 256 ordered-float steps, such that at least k values are >= t; 0 when fewer than k are set.  Any
-// such t is good for a cut, so the search gallops down from the maximum (the k-th largest of a set of maxima sits a
-// few 2^-10 of it away) and bisects what is left: ~15 probes of XV compares + wave votes instead of a sort.
-template <int XV>
-__device__ __forceinline__ uint32_t wave_kth_bound(const uint32_t (&v)[XV], int k) {
+// Maximum over the 64 lanes of a wave, returned in every lane (wave-uniform).  Six DPP steps on the VALU (row shifts, then
+// the row broadcasts of GFX9) and one v_readlane: ~60 cycles, where six ds_bpermute exchanges cost ~700
+// (tools/dpp_reduce_check.hip checks it against the shuffle reduction on the device).
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#define LBH_DPP_MAX(ctrl)                                                                              \
+    {                                                                                                  \
+        const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xF, 0xF, false);    \
+        v = t > v ? t : v;                                                                             \
+    }
+    LBH_DPP_MAX(0x111) LBH_DPP_MAX(0x112) LBH_DPP_MAX(0x114) LBH_DPP_MAX(0x118)  // row_shr 1, 2, 4, 8: lane 15 of a row holds the row's maximum
+    LBH_DPP_MAX(0x142) LBH_DPP_MAX(0x143)                                        // row_bcast 15, 31: lane 63 holds the wave's
+#undef LBH_DPP_MAX
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Wave-uniform lower bound of the k-th largest of the 64 x XV values the lanes of a wave hold (0 = an empty slot): a t,
+// at most 2^PREC ordered-float steps below the k-th largest, such that at least k values are >= t; 0 when fewer than k
+// are set.  Any such t is good for a cut, so the search gallops down from the maximum (the k-th largest of a set of
+// maxima sits a few 2^-10 of it away) and bisects what is left: a dozen probes of XV compares + wave votes, no sort.
+// `floor`: values at or below it are of no use to the caller (its current cut) -- one probe there ends the search early.
+template <int XV, int PREC = 8>
+__device__ __forceinline__ uint32_t wave_kth_bound(const uint32_t (&v)[XV], int k, uint32_t floor = 0) {
     auto count = [&](uint32_t t) {
         int c = 0;
 #pragma unroll
@@ -234,21 +250,18 @@ __device__ __forceinline__ uint32_t wave_kth_bound(const uint32_t (&v)[XV], int 
     uint32_t hi = 0;
 #pragma unroll
     for (int i = 0; i < XV; ++i) hi = v[i] > hi ? v[i] : hi;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t t = (uint32_t)__shfl_xor((int)hi, o);
-        hi = t > hi ? t : hi;
-    }
-    if (hi == 0) return 0;
+    hi = wave_max_u32(hi);
+    if (hi <= floor) return 0;
+    if (floor && count(floor + 1) < k) return 0;
     if (count(hi) >= k) return hi;
-    uint32_t lo = 0;  // count(lo) >= k holds for lo = 0 by convention ("no bound"); hi: count(hi) < k
+    uint32_t lo = floor;  // count(lo) >= k holds (by the probe above, or by convention for 0: "no bound"); count(hi) < k
     for (uint32_t step = 1u << 14; step; step <<= 2) {
-        const uint32_t probe = hi > step ? hi - step : 0u;
-        if (probe == 0u) break;
+        const uint32_t probe = hi - lo > step ? hi - step : lo;
+        if (probe == lo) break;
         if (count(probe) >= k) { lo = probe; break; }
         hi = probe;
     }
-    while (hi - lo > 256u) {
+    while (hi - lo > (1u << PREC)) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
         if (count(mid) >= k) lo = mid; else hi = mid;
     }
@@ -326,12 +339,7 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
         if (2 * k < trigger) trigger = 2 * k < 64 ? 64 : 2 * k;  // the shared bound does not need 4 k rows of this wave
     }
     auto xb_publish = [&]() {
-        uint32_t wm = omax;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t t = (uint32_t)__shfl_xor((int)wm, o);
-            wm = t > wm ? t : wm;
-        }
+        const uint32_t wm = wave_max_u32(omax);
         if (lane == 0 && wm > wpub) {
             const uint32_t old = atomicMax(&sh_bmax, wm);
             if (wm > old && (int)blockIdx.x < LBH_XB_SLOTS)
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
             if (b < xg) w = __hip_atomic_load(&xslot[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             v[i] = (uint32_t)(w >> 32) == (uint32_t)seq ? (uint32_t)w : 0u;
         }
-        return wave_kth_bound<XV>(v, k);
+        return wave_kth_bound<XV>(v, k, thr);  // a bound at or below the current threshold is of no use
     };
 
     // sort the wave buffer, raise the threshold, drop what fell below it
@@ -481,7 +489,70 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
         }
     }
     K2_STAMP(1);
-    if (!dead && cnt > 0) compact(false);
+    // the other blocks' cuts (see the block merge below): a device-scope load takes 1-2 us to come back, so it goes out now
+    uint32_t gseen = 0;
+    if (wave == 0) gseen = __hip_atomic_load(reinterpret_cast<unsigned int*>(&flags[64]) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Final cut of the wave's buffer: no sort (the block's merged list is sorted below anyway) -- a lower bound of the k-th
+    // best of the <= 256 entries from a dozen wave votes (wave_kth_bound; the register sort's cross-lane exchanges took
+    // 1.1-1.6 us at the end of every block), survivors stay in registers until the block knows where they go.
+    uint64_t fe[LBH_WCAP / 64];
+    bool fk[LBH_WCAP / 64];
+#pragma unroll
+    for (int r = 0; r < LBH_WCAP / 64; ++r) { fe[r] = 0; fk[r] = false; }
+    if (!dead && cnt > 0) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < LBH_WCAP / 64; ++r) fe[r] = (r * 64 + lane) < cnt ? buf[r * 64 + lane] : 0ull;
+        if (cnt >= k) {
+            uint32_t b;
+            if (cnt <= 128) {
+                // the usual case: the exact k-th best by rank counting from broadcast LDS reads (entries are unique) -- the
+                // lane that finds k - 1 entries above one of its own holds it
+                int r0 = 0, r1 = 0;
+                int j = 0;
+                for (; j + 4 <= cnt; j += 4) {
+                    const uint64_t a = buf[j], bb = buf[j + 1], c2 = buf[j + 2], d = buf[j + 3];
+                    r0 += (int)(a > fe[0]) + (int)(bb > fe[0]) + (int)(c2 > fe[0]) + (int)(d > fe[0]);
+                    r1 += (int)(a > fe[1]) + (int)(bb > fe[1]) + (int)(c2 > fe[1]) + (int)(d > fe[1]);
+                }
+                for (; j < cnt; ++j) {
+                    const uint64_t a = buf[j];
+                    r0 += (int)(a > fe[0]);
+                    r1 += (int)(a > fe[1]);
+                }
+                const bool h0 = lane < cnt && r0 == k - 1, h1 = lane + 64 < cnt && r1 == k - 1;
+                const uint32_t mine = h0 ? (uint32_t)(fe[0] >> 32) : (h1 ? (uint32_t)(fe[1] >> 32) : 0u);
+                b = wave_max_u32(mine);  // exactly one lane holds a non-zero value
+            } else {
+                uint32_t v4[LBH_WCAP / 64];
+#pragma unroll
+                for (int r = 0; r < LBH_WCAP / 64; ++r) v4[r] = (uint32_t)(fe[r] >> 32);
+                b = wave_kth_bound<LBH_WCAP / 64>(v4, k);
+            }
+            if (b) {
+                const uint32_t nt = lbh_ord32(lbh_unord32(b) - margin);
+                if (nt > thr) thr = nt;
+            }
+        }
+        int kept = 0;
+#pragma unroll
+        for (int r = 0; r < LBH_WCAP / 64; ++r) {
+            fk[r] = (r * 64 + lane) < cnt && (uint32_t)(fe[r] >> 32) >= thr;
+            kept += __popcll(__ballot(fk[r]));
+        }
+        cnt = kept;
+        if (cnt > LBH_WCAP - 64) {  // more near-ties than the buffer holds: let the exact path decide
+            if (lane == 0) {
+                if (fuse) atomicOr(reinterpret_cast<unsigned long long*>(&flags[LBH_FLAG_TICKET]), LBH_TICKET_OVERFLOW);
+                else atomicOr(&flags[0], 1);
+            }
+            cnt = 0;
+#pragma unroll
+            for (int r = 0; r < LBH_WCAP / 64; ++r) fk[r] = false;
+        }
+    } else {
+        cnt = 0;
+    }
     K2_STAMP(2);
     if (lane == 0) wcnt[wave] = cnt;
     __syncthreads();
@@ -494,7 +565,15 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
         if (w < wave) off += wcnt[w];
         total += wcnt[w];
     }
-    for (int i = lane; i < cnt; i += 64) mbuf[off + i] = buf[i];
+    {
+        int pos = off;
+#pragma unroll
+        for (int r = 0; r < LBH_WCAP / 64; ++r) {
+            const uint64_t m = __ballot(fk[r]);
+            if (fk[r]) mbuf[pos + __popcll(m & lt_mask)] = fe[r];
+            pos += __popcll(m);
+        }
+    }
     const int n2 = pow2_at_least(total, 64);
     for (int i = total + threadIdx.x; i < n2; i += LBH_SCAN_THREADS) mbuf[i] = 0;
     __syncthreads();
@@ -511,15 +590,9 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
     // The slots are read FIRST (the load is in flight while the merged list is sorted) and the block's own cut is stored
     // LAST, with nothing waiting for it: a device-scope 4-byte store takes microseconds to complete, and behind it in the
     // same wave's memory queue the load of the slots cost every block 5-8 us of its tail.
-    uint32_t gseen = 0;
-    if (wave == 0) gseen = __hip_atomic_load(&gslot[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (issued by wave 0 right after its loop, ahead of the final cut and the block's barriers: see gseen above)
     auto shared_cut = [&](uint32_t own) -> uint32_t {  // wave 0 only
-        uint32_t g = gseen;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t t = (uint32_t)__shfl_xor((int)g, o);
-            g = t > g ? t : g;
-        }
+        const uint32_t g = wave_max_u32(gseen);
         return g > own ? g : own;
     };
     auto publish_cut = [&](uint32_t own) {
@@ -538,7 +611,31 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
     if (LBH_SCAN_WAVE_EPI && total <= 128) {
         // the usual case (each wave kept ~k rows): one wave sorts the merged list, no more block barriers
         if (wave == 0) {
-            wave_sort_desc_dispatch(mbuf, total, n2, lane);
+            // sort by rank counting: a lane holds entries lane and lane + 64 and counts the entries above each from
+            // broadcast LDS reads (independent loads, pipelined; entries are unique, so the ranks are a permutation), then
+            // writes its entries at their ranks into the other half of the merge buffer.  ~40 entries for top-8: 0.3 us,
+            // where the bitonic network's cross-lane exchanges took 1.1-1.8 (a v_readlane loop: 1.6 -- every step waits
+            // for the scalar result of the one before).
+            {
+                const uint64_t e0 = lane < total ? mbuf[lane] : 0ull, e1 = lane + 64 < total ? mbuf[lane + 64] : 0ull;
+                int r0 = 0, r1 = 0;
+                int j = 0;
+                for (; j + 4 <= total; j += 4) {
+                    const uint64_t a = mbuf[j], b = mbuf[j + 1], c2 = mbuf[j + 2], d = mbuf[j + 3];
+                    r0 += (int)(a > e0) + (int)(b > e0) + (int)(c2 > e0) + (int)(d > e0);
+                    r1 += (int)(a > e1) + (int)(b > e1) + (int)(c2 > e1) + (int)(d > e1);
+                }
+                for (; j < total; ++j) {
+                    const uint64_t a = mbuf[j];
+                    r0 += (int)(a > e0);
+                    r1 += (int)(a > e1);
+                }
+                uint64_t* srt = mbuf + 2 * LBH_WCAP;  // the merge buffer holds 4 x LBH_WCAP entries; this path uses <= 128
+                if (lane < total) srt[r0] = e0;
+                if (lane + 64 < total) srt[r1] = e1;
+                __builtin_amdgcn_wave_barrier();
+                mbuf = srt;
+            }
             uint32_t own = 0;
             if (total >= k) own = lbh_ord32(lbh_unord32((uint32_t)(mbuf[k - 1] >> 32)) - margin);
             const uint32_t bthr = shared_cut(own);
@@ -661,26 +758,38 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
     // The true top-k rows pass every such cut, so whatever else is dropped cannot change the result.  Every wave works
     // both out for itself from the same values (wave_kth_bound: a dozen probes), so one barrier -- bm complete -- is all
     // the block needs here.
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t t = (uint32_t)__shfl_xor((int)gcut, o);
-        gcut = t > gcut ? t : gcut;
-    }
+    gcut = wave_max_u32(gcut);
     __syncthreads();
+    // (2) only matters above (1): the search starts with one probe at the score (1) stands for, and stops at 2^-12 of the
+    // range (a cut 2^-13 looser than it might be lets no extra row through in practice)
+    const uint32_t cut_floor = gcut ? lbh_ord32(lbh_unord32(gcut) + margin) : 0u;
     uint32_t kth_of_maxima;
     if (GB <= 256) {  // one block per CU: four values per lane, half the work per probe
         uint32_t bv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) bv[i] = (i * 64 + lane) < GB ? bm[i * 64 + lane] : 0u;
-        kth_of_maxima = wave_kth_bound<4>(bv, k);
+        kth_of_maxima = wave_kth_bound<4, 12>(bv, k, cut_floor);
     } else {
         uint32_t bv[LBH_XB_SLOTS / 64];
 #pragma unroll
         for (int i = 0; i < LBH_XB_SLOTS / 64; ++i) bv[i] = (i * 64 + lane) < GB ? bm[i * 64 + lane] : 0u;
-        kth_of_maxima = wave_kth_bound<LBH_XB_SLOTS / 64>(bv, k);
+        kth_of_maxima = wave_kth_bound<LBH_XB_SLOTS / 64, 12>(bv, k, cut_floor);
     }
     const uint32_t precut2 = kth_of_maxima ? lbh_ord32(lbh_unord32(kth_of_maxima) - margin) : 0u;
     K4_STAMP(12);  // cuts known
+#ifdef LBH_K2_TIMING
+    // the same computation twice more through ONE copy of the code: the first pass fetches it, the second finds it cached
+#pragma unroll 1
+    for (int rep = 0; rep < 2; ++rep) {
+        uint32_t bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = (i * 64 + lane) < GB ? bm[i * 64 + lane] : 0u;
+        asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
+        const uint32_t again = wave_kth_bound<4, 12>(bv, k + (rep >> 4), cut_floor);
+        if (again == 0xFFFFFFFFu) sh_stage = 1;  // never: keeps the computation alive
+        if (threadIdx.x == 0) lbh_k4_dbg[13 + rep] = wall_clock64();
+    }
+#endif
     constexpr int STAGE_CAP = 2 * LBH_SCAN_WAVES * LBH_WCAP;
     if (!overflowed) {
         const uint32_t precut = gcut > precut2 ? gcut : precut2;

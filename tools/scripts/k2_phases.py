@@ -68,4 +68,6 @@ if hasattr(lib, "lbh_debug_k4_times"):
           % tuple(m[2:]))
     if k4[11]:
         print("    fused tail, after the ticket: loads back +%.2f us, cuts known +%.2f us" % ((k4[11] - k4[0]) / 100.0, (k4[12] - k4[0]) / 100.0))
+        if k4[13]:
+            print("    the k-th-largest bound computed twice more through one copy of the code: %.2f us (code fetched), %.2f us (cached)" % ((k4[13] - k4[12]) / 100.0, (k4[14] - k4[13]) / 100.0))
     print("    candidates in the flat list E = %d, kept for the exact re-rank M = %d (last search); staged by a fused scan's last block after its pre-cut: %d" % (k4[8], k4[9], k4[10]))
