@@ -81,12 +81,16 @@ int lbh_device_name(lbh_ctx* ctx, char* buf, int buflen);
  * matrix, 256 B/claim, default; 1 = scan a 128 B/claim fp16 copy that the index builds on first
  * use, wider candidate margin, unit-scale data only - results are the same either way, the
  * re-rank is always exact fp64), "bq_mode" (batched scan precision: 0 fp32 MFMA, 1 split bf16,
- * 2 fp16 = default), "spin_us" (completion-ticket polling budget), "coll_timeout_ms" (longest wait for a
+ * 2 fp16 = default), "scan_fuse" (0 / 1 / 2: the single-query scan's last block runs the select step itself -- never /
+ * for grids of one block per CU on indexes up to 4 M claims, the default / always), "scan_xb_k" (smallest top_k for
+ * which the scan's waves share a cross-block threshold at their compactions, default 24, 0 = never), "k1_memo_log2"
+ * (log2 of the entries of the vectoriser's token -> digest table, default 20 = 128 MiB of HBM, 0 = off),
+ * "spin_us" (completion-ticket polling budget), "coll_timeout_ms" (longest wait for a
  * claim-sharded search's all-gather; also LBH_COLL_TIMEOUT_MS), "force_exact" (0/1, diagnostic: single-query searches rank with the exact fp64 scan only -- the
  * path that otherwise serves mass ties and result pages beyond the first), "inject_fault" (test hook, one-shot: 1 = the next
  * sharded search's local part fails on this rank, 2 = its stream is held up past the timeout).  Also read from the
  * environment at lbh_init as LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT / LBH_SCAN_MODE /
- * LBH_BQ_MODE / LBH_SPIN_US; environment only: LBH_SCAN_SPLIT ("a,b,c,d": tile shares of the scan's
+ * LBH_BQ_MODE / LBH_SPIN_US / LBH_SCAN_FUSE / LBH_SCAN_XB_K / LBH_K1_MEMO_LOG2; environment only: LBH_SCAN_SPLIT ("a,b,c,d": tile shares of the scan's
  * four block classes, "0": grid-stride loop). */
 int lbh_set_option(lbh_ctx* ctx, const char* name, int64_t value);
 
