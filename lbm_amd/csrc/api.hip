@@ -48,6 +48,7 @@ int fail(int code, const char* fmt, ...) {
 
 }  // namespace
 
+#define LBH_QUERY_ZERO_COPY_MAX 8192  // lbh_index_search_text: queries up to this many bytes are read by K1 straight from mapped host memory
 #define LBH_ADD_SLICES 4  // most slices one lbh_index_add call is cut into
 
 struct lbh_ctx {
@@ -69,6 +70,7 @@ struct lbh_ctx {
     uint64_t* memo_table = nullptr;
     uint32_t memo_mask = 0;
     uint32_t memo_epoch = 0;       // launches that used the table so far (a launch trusts only entries of earlier ones)
+    int add_cuts = 0;      // option "add_cuts" (experiments): cuts of lbh_index_add's four text slices, a * 10000 + b * 100 + c sixteenths; 0 = built-in
     int scan_xb_k = 24;    // option "scan_xb_k": smallest top_k for which the scan's waves share a cross-block bound at their compactions (0 = never)
     int scan_fuse = 1;     // option "scan_fuse": the scan's last block runs the select step itself -- 0 never, 1 = when the grid is one block per CU (default), 2 always
     int force_exact = 0;   // option "force_exact" (diagnostic / parity tests): single-query searches skip the fp32 scan and rank with the exact fp64 scan
@@ -98,7 +100,8 @@ struct lbh_slot {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t stream = nullptr;  // slot 0: the context's stream; further slots: their own
     bool own_stream = false;
-    void* staging = nullptr;      // pinned host staging of the query text
+    void* staging = nullptr;      // pinned host staging of the query text (device-mapped, coherent: K1 reads a short query from it directly)
+    void* staging_dev = nullptr;  // the same memory as the device sees it
     int64_t staging_cap = 0;
     uint8_t* d_text = nullptr;    // query text on the device (search_text)
     int64_t d_text_cap = 0;
@@ -311,10 +314,11 @@ void slot_destroy(lbh_slot* sl) {
 int slot_text_buffers(lbh_slot* sl, int64_t bytes) {
     if (bytes > sl->staging_cap) {
         if (sl->staging) (void)hipHostFree(sl->staging);
-        sl->staging = nullptr;
+        sl->staging = sl->staging_dev = nullptr;
         sl->staging_cap = 0;
         const int64_t cap = std::max<int64_t>(bytes, 1 << 16);
-        HIP_TRY(hipHostMalloc(&sl->staging, (size_t)cap, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&sl->staging, (size_t)cap, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostGetDevicePointer(&sl->staging_dev, sl->staging, 0));
         sl->staging_cap = cap;
     }
     if (bytes > sl->d_text_cap) {
@@ -833,6 +837,11 @@ int lbh_set_option(lbh_ctx* c, const char* name, int64_t value) {
         }
         c->memo_log2 = lg;
     }
+    else if (!strcmp(name, "add_cuts")) {
+        const int a = (int)(value / 10000 % 100), b = (int)(value / 100 % 100), d = (int)(value % 100);
+        if (value != 0 && !(0 < a && a < b && b < d && d < 16)) return fail(LBH_E_INVALID, "add_cuts: need 0 < a < b < c < 16 as a * 10000 + b * 100 + c");
+        c->add_cuts = (int)value;
+    }
     else if (!strcmp(name, "scan_xb_k")) c->scan_xb_k = (int)std::max<int64_t>(0, std::min<int64_t>(1 << 20, value));
     else if (!strcmp(name, "scan_fuse")) c->scan_fuse = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else if (!strcmp(name, "force_exact")) c->force_exact = value != 0;
@@ -1049,11 +1058,18 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
         // slice i on the compute stream (offsets stay absolute into the one text blob, so a slice is just a pointer pair).
         // K1 needs none of the metadata columns, so those follow the LAST slice of text on the copy stream and arrive under
         // K1 as well (ahead of the text they kept K1 waiting for 48 bytes per claim: 1.1 of 6.4 ms per million claims).
-        // Slices grow geometrically: a short first one lets K1 start after 1/16 of the text has crossed, and every later
-        // slice's copy ends before the K1 launch ahead of it does (PCIe moves a claim's ~170 bytes in half of K1's time per
-        // claim) -- few, large launches, because each K1 launch pays its own ramp and tail (8 equal slices of a 1 M-claim
-        // batch took 8 x 0.61 ms against 4.1 ms in one launch).
-        static const int cut16[LBH_ADD_SLICES][LBH_ADD_SLICES + 1] = {{0, 16}, {0, 4, 16}, {0, 2, 6, 16}, {0, 1, 3, 7, 16}};
+        // Few, large launches, because each K1 launch pays its own ramp and tail (8 equal slices of a 1 M-claim batch took
+        // 8 x 0.61 ms against 4.1 ms in one launch).  A short first slice lets K1 start early; the LAST slice must not be the
+        // largest any more: since the token memo K1 outruns the link (2.3 against 2.9 ms per million claims), so what
+        // matters is how much K1 work is left when the last text byte has arrived -- 5/16 of the batch hides under the
+        // metadata copies, the 9/16 of the round-2 cuts (1, 3, 7 sixteenths: made for a K1 slower than the link) did not:
+        // 3.91 -> 3.45-3.85 ms per 1 M-claim call, and 4.60 -> 4.50 with the memo off (tools/ingest_ab.py).
+        int cut16[LBH_ADD_SLICES][LBH_ADD_SLICES + 1] = {{0, 16}, {0, 4, 16}, {0, 2, 6, 16}, {0, 2, 6, 11, 16}};
+        if (c->add_cuts > 0) {  // option "add_cuts" = a * 10000 + b * 100 + c: the four-slice cuts in sixteenths
+            cut16[3][1] = c->add_cuts / 10000 % 100;
+            cut16[3][2] = c->add_cuts / 100 % 100;
+            cut16[3][3] = c->add_cuts % 100;
+        }
         const int n_sl = (int)std::max<int64_t>(1, std::min<int64_t>(LBH_ADD_SLICES, n / 65536));
         for (int sl = 0; sl < n_sl; ++sl) {
             const int64_t a = n * cut16[n_sl - 1][sl] / 16, b2 = n * cut16[n_sl - 1][sl + 1] / 16;
@@ -1494,10 +1510,17 @@ int lbh_index_search_text(lbh_index* ix, const uint8_t* utf8, int64_t len, int64
     ho[1] = len;
     uint8_t* ht = reinterpret_cast<uint8_t*>(ho + 2);
     if (len) memcpy(ht, utf8, (size_t)len);
-    if (len) HIP_TRY(hipMemcpyAsync(sl->d_text, ht, (size_t)len, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(sl->d_off, ho, 16, hipMemcpyHostToDevice, s));
-    // embed(query) (lb/context_graph.py:104) straight into the search workspace
-    HIP_TRY(lbh_launch_embed(sl->d_text, sl->d_off, 1, sl->ws.q64, nullptr, s));
+    // embed(query) (lb/context_graph.py:104) straight into the search workspace.  A query of ordinary length is read by K1
+    // from the mapped staging area itself (a few hundred bytes over PCIe inside the kernel: ~2 us) -- two copy-engine
+    // hops ahead of the kernel cost the text entry ~10 us of stream time; long texts take the device copy.
+    if (len <= LBH_QUERY_ZERO_COPY_MAX) {
+        const int64_t* d_ho = reinterpret_cast<const int64_t*>(sl->staging_dev);
+        HIP_TRY(lbh_launch_embed(reinterpret_cast<const uint8_t*>(d_ho + 2), d_ho, 1, sl->ws.q64, nullptr, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(sl->d_text, ht, (size_t)len, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(sl->d_off, ho, 16, hipMemcpyHostToDevice, s));
+        HIP_TRY(lbh_launch_embed(sl->d_text, sl->d_off, 1, sl->ws.q64, nullptr, s));
+    }
     sl->qptr = sl->ws.q64;
     sl->qnorm = 1.0;  // K1 output: a unit vector (or zero)
     if (out_qvec64) {
