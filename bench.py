@@ -47,6 +47,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+READ_ONLY_KERNEL_GBS = 6950.0  # what a read-only streaming kernel reaches on this part (tools/hbm_read_rate.hip: 6.8-7.04 TB/s, profiles/r03_hbm_read_rate.txt)
 
 
 def parse():
@@ -539,7 +540,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": live * bytes_per_row, "kernel": "scan_f32_kernel",
                          "bytes_per_claim": bytes_per_row, "avg_kernel_us": avg_scan_s * 1e6,
-                         "timed_launches": n_timed},
+                         "timed_launches": n_timed,
+                         "read_only_kernel_GBs": READ_ONLY_KERNEL_GBS, "frac_of_read_only_kernel": achieved / READ_ONLY_KERNEL_GBS,
+                         "read_only_kernel_source": "profiles/r03_hbm_read_rate.txt (tools/hbm_read_rate.hip, same access pattern without the arithmetic; not measured in this run)"},
             "vectorise": {"claims_per_s_incl_h2d": my_claims / t_add if t_add > 0 else None,
                           "claims_per_s_incl_h2d_after_first_chunk":
                               (my_claims - min(chunk, my_claims)) / (t_add - t_add_first) if n_chunks > 1 else None,
