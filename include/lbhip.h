@@ -63,7 +63,8 @@ typedef struct lbh_stats {
     float total_ms;           /* out: HIP-event time of everything enqueued by the call (want_timing >= 2, else 0) */
     float max_score_err;      /* out: largest |scan score - exact fp64 score| over the rows that were re-scored: a live
                                  check of the scan's error bound (must stay below half the candidate margin) */
-    int32_t reserved;
+    float margin;             /* out, batched searches: the candidate margin the scan kernels worked with (2 x their error bound;
+                                 a constant per scan precision, derived from the index and the queries in the int8 mode) */
 } lbh_stats;
 
 /* ---- context -------------------------------------------------------------- */
@@ -81,7 +82,7 @@ int lbh_device_name(lbh_ctx* ctx, char* buf, int buflen);
  * matrix, 256 B/claim, default; 1 = scan a 128 B/claim fp16 copy that the index builds on first
  * use, wider candidate margin, unit-scale data only - results are the same either way, the
  * re-rank is always exact fp64), "bq_mode" (batched scan precision: 0 fp32 MFMA, 1 split bf16,
- * 2 fp16 = default), "scan_fuse" (0 / 1 / 2: the single-query scan's last block runs the select step itself -- never /
+ * 2 fp16 = default, 3 int8 on a 64 B/claim copy, margin derived per batch from the index's and the queries' scales), "scan_fuse" (0 / 1 / 2: the single-query scan's last block runs the select step itself -- never /
  * for grids of one block per CU on indexes up to 4 M claims, the default / always), "scan_xb_k" (smallest top_k for
  * which the scan's waves share a cross-block threshold at their compactions, default 24, 0 = never), "k1_memo_log2"
  * (log2 of the entries of the vectoriser's token -> digest table, default 20 = 128 MiB of HBM, 0 = off),

@@ -49,7 +49,7 @@ class Stats(ctypes.Structure):
         ("rows_scanned", ctypes.c_int64), ("bytes_per_row", ctypes.c_int64), ("candidates", ctypes.c_int64),
         ("scan_launches", ctypes.c_int32), ("fallbacks", ctypes.c_int32),
         ("scan_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
-        ("max_score_err", ctypes.c_float), ("reserved", ctypes.c_int32),
+        ("max_score_err", ctypes.c_float), ("margin", ctypes.c_float),
     ]
 
     def as_dict(self):

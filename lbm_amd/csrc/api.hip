@@ -129,6 +129,10 @@ struct lbh_index {
     uint64_t* ids = nullptr;      // per-row claim id (device mirror of id_of_row: the sharded search emits global ids on the GPU)
     uint16_t* emb16 = nullptr;    // fp16 copy in MFMA-fragment order (lbh_emb16_off), built on first use; rows [0, emb16_rows) are valid
     int64_t emb16_rows = 0, emb16_cap = 0;
+    int8_t* emb8 = nullptr;       // int8 copy in MFMA-fragment order (lbh_emb8_off) for the int8 batched scan; rows [0, emb8_rows) are valid
+    int64_t emb8_rows = 0, emb8_cap = 0;
+    double emb8_scale = 0.0;      // x ~ emb8_scale * X for every element of every converted row (|x| <= 127 emb8_scale)
+    uint32_t* emb8_absmax = nullptr;  // device word: float bits of the largest |element| of the rows being converted
     std::vector<uint64_t> id_of_row;
     std::vector<int64_t> row_of_id;
     double max_norm = 0.0;    // largest |x| ever added: the scans' error bounds (hence their candidate margins) scale with it
@@ -230,6 +234,11 @@ int index_reserve_locked(lbh_index* ix, int64_t want) {
         ix->emb16 = nullptr;
         ix->emb16_rows = ix->emb16_cap = 0;
     }
+    if (ix->emb8) {  // likewise
+        (void)hipFree(ix->emb8);
+        ix->emb8 = nullptr;
+        ix->emb8_rows = ix->emb8_cap = 0;
+    }
     try {  // the host-side id maps grow with the device columns, so that no ingest call pays a vector re-allocation
         ix->id_of_row.reserve((size_t)want);
         if (ix->row_of_id.capacity() < ix->row_of_id.size() + (size_t)(want - ix->n))
@@ -263,6 +272,7 @@ int ensure_dscratch(lbh_index* ix, int64_t bytes) {
 }
 
 // ---- slots and locks -------------------------------------------------------------------------------------------
+constexpr int LBH_NEED_EMB8 = -1001;   // ... the int8 copy
 constexpr int LBH_NEED_EMB16 = -1000;  // internal: a search found the fp16 copy out of date; rebuilt under the exclusive lock, then retried
 
 int slot_create(lbh_index* ix, int which, lbh_slot** out) {
@@ -296,7 +306,7 @@ void slot_destroy(lbh_slot* sl) {
     if (sl->stream) (void)hipStreamSynchronize(sl->stream);
     lbh_workspace& w = sl->ws;
     void* dev[] = {w.rc_a, w.rc_b, w.rc_row, w.rc_cnt, w.q64, w.cand, w.xcand_ord, w.xcand_row, w.flags, w.bmax,
-                   w.bq_qmat, w.bq_cand, w.bq_total, w.bq_seed, w.bq_bfrag, sl->d_text, sl->d_off};
+                   w.bq_qmat, w.bq_cand, w.bq_total, w.bq_seed, w.bq_bfrag, w.bq_qscale, sl->d_text, sl->d_off};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     for (auto& ev : sl->ev)
@@ -410,6 +420,7 @@ struct Exclusive {
 };
 
 int ensure_emb16(lbh_index* ix);
+int ensure_emb8(lbh_index* ix);
 
 // run a search body under a lease; when it reports the fp16 copy out of date, bring it up to date exclusively and retry
 template <class Body>
@@ -425,17 +436,19 @@ int with_lease(lbh_index* ix, Body&& body) {
             if (rc) return rc;
             rc = body(lease.slot());
         }
-        if (rc != LBH_NEED_EMB16) return rc;
-        if (attempt >= 8) return fail(LBH_E_INTERNAL, "the fp16 copy kept going out of date under concurrent writers");
+        if (rc != LBH_NEED_EMB16 && rc != LBH_NEED_EMB8) return rc;
+        if (attempt >= 8) return fail(LBH_E_INTERNAL, "the fp16 / int8 copy kept going out of date under concurrent writers");
+        const bool want8 = rc == LBH_NEED_EMB8;
         Exclusive w(ix);
         HIP_TRY(hipSetDevice(ix->ctx->device));
-        rc = ensure_emb16(ix);
+        rc = want8 ? ensure_emb8(ix) : ensure_emb16(ix);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(ix->ctx->stream));
     }
 }
 
 inline bool emb16_current(const lbh_index* ix) { return ix->emb16 && ix->emb16_rows == ix->n && ix->emb16_cap >= ix->cap; }
+inline bool emb8_current(const lbh_index* ix) { return ix->emb8 && ix->emb8_rows == ix->n && ix->emb8_cap >= ix->cap; }
 
 lbh_dev_index dev_view(const lbh_index* ix) {
     lbh_dev_index d;
@@ -536,6 +549,53 @@ int ensure_emb16(lbh_index* ix) {
     if (ix->emb16_rows < ix->n) {
         HIP_TRY(lbh_launch_f64_to_f16_tiled(ix->emb64, ix->emb16, ix->emb16_rows, ix->n, s));
         ix->emb16_rows = ix->n;
+    }
+    return LBH_OK;
+}
+
+// int8 copy (tiled, lbh_emb8_off) for the int8 batched scan.  ONE scale serves the whole index: the largest |element| of
+// the rows to convert is found first; while it fits the current scale only the new rows are converted, else every row is
+// converted again under a scale with 1/16 of headroom (after the first batch of a corpus this does not happen again in
+// practice: element magnitudes are a property of the embedding, not of the claim).  Called under the exclusive lock.
+int ensure_emb8(lbh_index* ix) {
+    hipStream_t s = ix->ctx->stream;
+    if (!ix->emb8 || ix->emb8_cap < ix->cap) {
+        if (ix->emb8) (void)hipFree(ix->emb8);
+        ix->emb8 = nullptr;
+        ix->emb8_rows = ix->emb8_cap = 0;
+        const size_t bytes = (size_t)((ix->cap + 31) / 32) * 32 * 64;
+        HIP_TRY(hipMalloc((void**)&ix->emb8, bytes));
+        HIP_TRY(hipMemsetAsync(ix->emb8, 0, bytes, s));
+        ix->emb8_cap = ix->cap;
+    }
+    if (!ix->emb8_absmax) HIP_TRY(hipMalloc((void**)&ix->emb8_absmax, 4));
+    if (ix->emb8_rows < ix->n) {
+        auto absmax = [&](int64_t r0, int64_t r1, float* out) -> int {
+            uint32_t bits = 0;
+            HIP_TRY(hipMemsetAsync(ix->emb8_absmax, 0, 4, s));
+            HIP_TRY(lbh_launch_absmax_f64(ix->emb64, r0, r1, ix->emb8_absmax, s));
+            HIP_TRY(hipMemcpyAsync(&bits, ix->emb8_absmax, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            memcpy(out, &bits, 4);
+            return LBH_OK;
+        };
+        float mx = 0.f;
+        int rc = absmax(ix->emb8_rows, ix->n, &mx);
+        if (rc) return rc;
+        if (!(mx <= 3.0e38f)) return fail(LBH_E_INTERNAL, "int8 copy: non-finite element in the matrix");
+        int64_t from = ix->emb8_rows;
+        if (ix->emb8_rows == 0 || (double)mx > 127.0 * ix->emb8_scale) {
+            if (ix->emb8_rows > 0) {  // the old rows count too
+                float mx_old = 0.f;
+                rc = absmax(0, ix->emb8_rows, &mx_old);
+                if (rc) return rc;
+                mx = std::max(mx, mx_old);
+            }
+            ix->emb8_scale = mx > 0.f ? (double)mx * 1.0625 / 127.0 : 1.0;
+            from = 0;
+        }
+        HIP_TRY(lbh_launch_f64_to_i8_tiled(ix->emb64, ix->emb8, from, ix->n, 1.0 / ix->emb8_scale, s));
+        ix->emb8_rows = ix->n;
     }
     return LBH_OK;
 }
@@ -671,6 +731,7 @@ int ensure_batched_ws(lbh_slot* sl) {
     if (!w.bq_total) HIP_TRY(hipMalloc((void**)&w.bq_total, (size_t)LBH_BQ_MAXQ * LBH_BQ_QT_STRIDE * 4));
     if (!w.bq_seed) HIP_TRY(hipMalloc((void**)&w.bq_seed, (size_t)LBH_BQ_MAXQ * 4));
     if (!w.bq_bfrag) HIP_TRY(hipMalloc((void**)&w.bq_bfrag, (size_t)LBH_BQ_MAXQ * 128));
+    if (!w.bq_qscale) HIP_TRY(hipMalloc((void**)&w.bq_qscale, (size_t)LBH_BQ_MAXQ * 4));
     if (!w.bq_result_host) {
         HIP_TRY(hipHostMalloc((void**)&w.bq_result_host, sizeof(lbh_result) * LBH_BQ_MAXQ, hipHostMallocMapped | hipHostMallocCoherent));
         memset(w.bq_result_host, 0, sizeof(lbh_result) * LBH_BQ_MAXQ);
@@ -774,7 +835,7 @@ int lbh_init(const int* devices, int n_devices, lbh_ctx** out_ctx) {
         const uint32_t ww[4] = {std::min(w[0], 65535u), std::min(w[1], 65535u), std::min(w[2], 65535u), std::min(w[3], 65535u)};
         if (got == 4 || got == 1) lbh_set_scan_split(ww);
     }
-    if (const char* e4 = getenv("LBH_BQ_MODE")) c->bq_mode = std::max(0, std::min(2, atoi(e4)));
+    if (const char* e4 = getenv("LBH_BQ_MODE")) c->bq_mode = std::max(0, std::min(3, atoi(e4)));
     if (const char* e3 = getenv("LBH_SPIN_US")) c->spin_us = std::max(0, std::min(1000000, atoi(e3)));
     if (const char* e9 = getenv("LBH_K1_MEMO_LOG2")) c->memo_log2 = atoi(e9) <= 0 ? 0 : std::max(8, std::min(24, atoi(e9)));
     if (const char* e9 = getenv("LBH_SCAN_XB_K")) c->scan_xb_k = std::max(0, atoi(e9));
@@ -824,7 +885,7 @@ int lbh_set_option(lbh_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "scan_blocks_per_cu")) c->scan_blocks_per_cu = (int)std::max<int64_t>(0, std::min<int64_t>(8, value));
     else if (!strcmp(name, "scan_nt")) c->scan_nt = value != 0;
     else if (!strcmp(name, "scan_mode")) c->scan_mode = value != 0;
-    else if (!strcmp(name, "bq_mode")) c->bq_mode = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
+    else if (!strcmp(name, "bq_mode")) c->bq_mode = (int)std::max<int64_t>(0, std::min<int64_t>(3, value));
     else if (!strcmp(name, "spin_us")) c->spin_us = (int)std::max<int64_t>(0, std::min<int64_t>(1000000, value));
     else if (!strcmp(name, "coll_timeout_ms")) c->coll_timeout_ms = (int)std::max<int64_t>(1, std::min<int64_t>(3600000, value));
     else if (!strcmp(name, "k1_memo_log2")) {
@@ -958,7 +1019,7 @@ int lbh_index_destroy(lbh_index* ix) {
         slot_destroy(sl);
         sl = nullptr;
     }
-    void* dev[] = {ix->emb16, ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, ix->order, ix->ids};
+    void* dev[] = {ix->emb16, ix->emb8, ix->emb8_absmax, ix->emb32, ix->emb64, ix->created, ix->tags, ix->keys, ix->order, ix->ids};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     if (ix->mut_ev) (void)hipEventDestroy(ix->mut_ev);
@@ -1120,7 +1181,8 @@ int lbh_index_retract(lbh_index* ix, uint64_t id) {
     HIP_TRY(hipSetDevice(ix->ctx->device));
     const int64_t r = ix->row_of_id[(size_t)id], last = ix->n - 1;
     if (r != last) {
-        HIP_TRY(lbh_launch_move_row(ix->emb32, ix->emb64, (ix->emb16 && ix->emb16_rows == ix->n) ? ix->emb16 : nullptr, ix->created, ix->tags, ix->keys, ix->order, ix->ids, r, last, ix->ctx->stream));
+        HIP_TRY(lbh_launch_move_row(ix->emb32, ix->emb64, (ix->emb16 && ix->emb16_rows == ix->n) ? ix->emb16 : nullptr,
+                                    (ix->emb8 && ix->emb8_rows == ix->n) ? ix->emb8 : nullptr, ix->created, ix->tags, ix->keys, ix->order, ix->ids, r, last, ix->ctx->stream));
         const uint64_t moved = ix->id_of_row[(size_t)last];
         ix->id_of_row[(size_t)r] = moved;
         ix->row_of_id[(size_t)moved] = r;
@@ -1129,6 +1191,8 @@ int lbh_index_retract(lbh_index* ix, uint64_t id) {
     ix->id_of_row.pop_back();
     if (ix->emb16_rows == ix->n) ix->emb16_rows = ix->n - 1;  // the copy followed the swap-delete
     else ix->emb16_rows = 0;                                   // rows were pending conversion: rebuild at next use
+    if (ix->emb8_rows == ix->n) ix->emb8_rows = ix->n - 1;
+    else ix->emb8_rows = 0;
     ix->n -= 1;
     return LBH_OK;
 }
@@ -1172,10 +1236,15 @@ int lbh_index_retract_many(lbh_index* ix, int64_t n, const uint64_t* ids) try {
             rc = ensure_emb16(ix);
             if (rc) return rc;
         }
+        if (ix->emb8 && ix->emb8_rows < ix->n) {  // likewise the int8 copy
+            rc = ensure_emb8(ix);
+            if (rc) return rc;
+        }
         rc = ensure_dscratch(ix, n_holes * 16);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(ix->dscratch, pairs, (size_t)n_holes * 16, hipMemcpyHostToDevice, s));
-        HIP_TRY(lbh_launch_move_rows(ix->emb32, ix->emb64, (ix->emb16 && ix->emb16_rows == ix->n) ? ix->emb16 : nullptr, ix->created,
+        HIP_TRY(lbh_launch_move_rows(ix->emb32, ix->emb64, (ix->emb16 && ix->emb16_rows == ix->n) ? ix->emb16 : nullptr,
+                                     (ix->emb8 && ix->emb8_rows == ix->n) ? ix->emb8 : nullptr, ix->created,
                                      ix->tags, ix->keys, ix->order, ix->ids, reinterpret_cast<const int64_t*>(ix->dscratch), n_holes, s));
         HIP_TRY(hipStreamSynchronize(s));  // the staging area is reused by the next call
     }
@@ -1188,6 +1257,8 @@ int lbh_index_retract_many(lbh_index* ix, int64_t n, const uint64_t* ids) try {
     ix->id_of_row.resize((size_t)n_new);
     if (ix->emb16_rows == n_old) ix->emb16_rows = n_new;  // the copy followed the moves
     else ix->emb16_rows = std::min(ix->emb16_rows, n_new);  // only reached without moves: the converted prefix stays valid
+    if (ix->emb8_rows == n_old) ix->emb8_rows = n_new;
+    else ix->emb8_rows = std::min(ix->emb8_rows, n_new);
     ix->n = n_new;
     return LBH_OK;
 } LBH_CATCH_ALLOC
@@ -1388,29 +1459,52 @@ int search_many(lbh_index* ix, lbh_slot* sl, const double* q_f64, int64_t nq, in
     // re-run below on the single-query path, so results never depend on which path served them.
     // top_k: the fp16 kernel keeps no per-query state in registers, so it serves any k of one result page (<= 64); the
     // fp32 / split-bf16 kernels keep k-entry lists per lane and stop at LBH_BQ_KMAX (larger k: single-query path below)
-    if (nq >= 3 && keff >= 1 && keff <= (ix->ctx->bq_mode == 2 ? LBH_MAX_PAGE : LBH_BQ_KMAX) && ix->n > 0) {
+    if (nq >= 3 && keff >= 1 && keff <= (ix->ctx->bq_mode >= 2 ? LBH_MAX_PAGE : LBH_BQ_KMAX) && ix->n > 0) {
         int rc = ensure_batched_ws(sl);
         if (rc) return rc;
         lbh_ctx* c = ix->ctx;
         hipStream_t s = sl->stream;
         const lbh_dev_index dv = dev_view(ix);
         const int has_since = since_ms != LBH_SINCE_NONE;
-        bool any16 = false;
+        bool any16 = false, any8 = false;
         for (int64_t q0 = 0; q0 < nq; q0 += LBH_BQ_MAXQ) {
             const int nb = (int)std::min<int64_t>(LBH_BQ_MAXQ, nq - q0);
             double qn = 0.0;
             for (int q = 0; q < nb; ++q) qn = std::max(qn, vec_norm(q_f64 + (q0 + q) * 64));
             if (!(qn <= 1e15)) return fail(LBH_E_INVALID, "a query vector is not finite (or its norm exceeds 1e15)");
             const float nscale = norm_scale(ix, qn);
+            // int8 mode (bq_mode 3): the int8 copy (64 B/claim) on v_mfma_i32_32x32x32_i8.  Its candidate margin comes from
+            // the error bound for THIS index and THESE queries (lbh_internal.h): with s the copy's scale and t_q = max|q_i| / 127,
+            // eps_q = (s/2)(|q|_1 + 32 t_q) + (t_q/2)(8 max|x| + 32 s) + 16 s t_q; margin = 2 max_q eps_q (+ 0.1 % and 1e-6 for the
+            // float arithmetic around it).  The scale is only known once the copy exists, so the copy comes first.
+            bool src8 = false;
+            float margin8 = 0.f;
+            if (c->bq_mode == 3 && qn > 0.0) {
+                if (!emb8_current(ix)) return LBH_NEED_EMB8;
+                const double sx = ix->emb8_scale;
+                double eps = 0.0;
+                for (int q = 0; q < nb; ++q) {
+                    const double* v = q_f64 + (q0 + q) * 64;
+                    double l1 = 0.0, mxq = 0.0;
+                    for (int d = 0; d < 64; ++d) { l1 += std::fabs(v[d]); mxq = std::max(mxq, std::fabs(v[d])); }
+                    if (mxq == 0.0) continue;  // a zero query scores every claim exactly 0 in either arithmetic
+                    const double t = mxq / 127.0;
+                    eps = std::max(eps, 0.5 * sx * (l1 + 32.0 * t) + 0.5 * t * (8.0 * ix->max_norm + 32.0 * sx) + 16.0 * sx * t);
+                }
+                margin8 = (float)(2.0 * eps * 1.001 + 1e-6);
+                src8 = margin8 <= LBH_I8_MARGIN_MAX * nscale;  // odd data (one huge component): the fp16 kernel's bound is tighter
+            }
             // the fp16 kernel streams the fp16 copy of the matrix (128 B/claim, MFMA-fragment order; built on first use)
-            const bool src16 = c->bq_mode == 2 && nscale >= 0.25f && nscale <= 1.001f;
-            if (!src16 && keff > LBH_BQ_KMAX) continue;  // data outside fp16's range with a large k: single-query path
+            const bool src16 = !src8 && c->bq_mode >= 2 && nscale >= 0.25f && nscale <= 1.001f;
+            if (!src8 && !src16 && keff > LBH_BQ_KMAX) continue;  // data outside fp16's range with a large k: single-query path
             if (src16 && !emb16_current(ix)) return LBH_NEED_EMB16;
             any16 = any16 || src16;
+            any8 = any8 || src8;
+            total.margin = std::max(total.margin, src8 ? margin8 : (src16 ? LBH_MARGIN_F16 : c->bq_mode >= 1 ? LBH_MARGIN_BF16X3 : LBH_MARGIN) * nscale);
             // The queries: the fp16 mode's first kernel reads them straight from device-mapped pinned memory (one host
             // memcpy, no copy-engine hop, no staging of pageable memory); the other modes take a device copy first.
             const double* q_src = sl->ws.bq_qmat;
-            if (src16) {
+            if (src16 || src8) {
                 memcpy(sl->ws.bq_qhost, q_f64 + q0 * 64, (size_t)nb * 512);
                 q_src = sl->ws.bq_qhost_dev;
             } else {
@@ -1418,7 +1512,8 @@ int search_many(lbh_index* ix, lbh_slot* sl, const double* q_f64, int64_t nq, in
             }
             const int32_t seq = sl->seq = (sl->seq == INT32_MAX) ? 1 : sl->seq + 1;
             HIP_TRY(lbh_launch_search_batched(dv, src16 ? ix->emb16 : nullptr, sl->ws, q_src, nb, (int)keff, has_since, since_ms, tag_mask, c->n_cu,
-                                              c->bq_mode, nscale, seq, s, timing ? sl->ev[0] : nullptr, timing ? sl->ev[1] : nullptr));
+                                              src8 ? 3 : std::min(c->bq_mode, 2), nscale, seq, s, timing ? sl->ev[0] : nullptr, timing ? sl->ev[1] : nullptr,
+                                              src8 ? ix->emb8 : nullptr, (float)ix->emb8_scale, margin8));
             // every query's select block publishes its own ticket into its result block (mapped host memory)
             for (int i = 0; i < nb; ++i) HIP_TRY(wait_ticket(c, s, &sl->ws.bq_result_host[i].seq, seq));
             if (timing) HIP_TRY(hipEventSynchronize(sl->ev[1]));
@@ -1445,7 +1540,7 @@ int search_many(lbh_index* ix, lbh_slot* sl, const double* q_f64, int64_t nq, in
             }
         }
         total.path = 2;
-        total.bytes_per_row = (any16 ? 128 : 256) + (has_since ? 8 : 0) + (tag_mask ? 8 : 0);
+        total.bytes_per_row = (any8 ? 64 : any16 ? 128 : 256) + (has_since ? 8 : 0) + (tag_mask ? 8 : 0);
     }
     for (int64_t q = 0; q < nq; ++q) {
         if (done[(size_t)q]) continue;
@@ -2008,7 +2103,7 @@ int lbh_index_search_sharded_many(lbh_index* ix, lbh_comm* cm, const double* q_f
     } else {
         lrc = search_many(ix, sl, q_f64, nq, k, since_ms, tag_mask, ids.data(), sc.data(), keys.data(), cnts.data(), stats);
     }
-    if (lrc == LBH_NEED_EMB16) return lrc;  // nothing of the exchange has been queued: fp16 copy rebuilt, body retried
+    if (lrc == LBH_NEED_EMB16 || lrc == LBH_NEED_EMB8) return lrc;  // nothing of the exchange has been queued: fp16 copy rebuilt, body retried
     int rc = ensure_staged(cm, (int64_t)bytes);  // an allocation failure here leaves the peers to their timeout
     if (rc) {
         cm->broken = true;

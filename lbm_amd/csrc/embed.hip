@@ -447,12 +447,50 @@ __global__ void f64_to_f16_tiled_kernel(const double* __restrict__ emb64, _Float
     }
 }
 
+// int8 copy, step 1: the largest |element| of rows [row0, row1) -> atomicMax on its float bits (non-negative floats order
+// like their bit patterns)
+__global__ void absmax_f64_kernel(const double* __restrict__ emb64, int64_t e0, int64_t e1, uint32_t* __restrict__ out_bits) {
+    float m = 0.f;
+    for (int64_t i = e0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e1; i += (int64_t)gridDim.x * blockDim.x) {
+        const float a = (float)__builtin_fabs(emb64[i]);
+        // round UP to float when the conversion rounded down: the scale derived from this must cover the double
+        const float up = ((double)a < __builtin_fabs(emb64[i])) ? lbh_next_up(a) : a;
+        m = up > m ? up : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(m, o);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out_bits, __builtin_bit_cast(uint32_t, m));
+}
+
+// int8 copy, step 2: X = rint(x * inv_scale), clamped to [-127, 127] (the scale covers every element, so the clamp only
+// guards against a caller's misuse), written in fragment order: one thread = 16 consecutive dims of one row = one 16-byte chunk
+__global__ void f64_to_i8_tiled_kernel(const double* __restrict__ emb64, int8_t* __restrict__ emb8, int64_t row0, int64_t row1, double inv_scale) {
+    const int64_t total = (row1 - row0) * 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = row0 + (i >> 2);
+        const int c = (int)(i & 3);  // dims 16 c .. 16 c + 15
+        const double* src = emb64 + row * 64 + c * 16;
+        union { int8_t b[16]; uint4 v; } u;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            int q = __double2int_rn(src[e] * inv_scale);
+            q = q > 127 ? 127 : (q < -127 ? -127 : q);
+            u.b[e] = (int8_t)q;
+        }
+        *reinterpret_cast<uint4*>(emb8 + lbh_emb8_off(row, c * 16)) = u.v;
+    }
+}
+
 // swap-delete support: copy row `src` over row `dst` in every per-claim array
-__global__ void move_row_kernel(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
+__global__ void move_row_kernel(float* emb32, double* emb64, uint16_t* emb16, int8_t* emb8, int64_t* created, uint64_t* tags, uint64_t* keys,
                                 uint64_t* order, uint64_t* ids, int64_t dst, int64_t src) {
     const int l = threadIdx.x;
     emb32[dst * 64 + l] = emb32[src * 64 + l];
     if (emb16) emb16[lbh_emb16_off(dst, l)] = emb16[lbh_emb16_off(src, l)];
+    if (emb8) emb8[lbh_emb8_off(dst, l)] = emb8[lbh_emb8_off(src, l)];
     emb64[dst * 64 + l] = emb64[src * 64 + l];
     if (l < 4) keys[dst * 4 + l] = keys[src * 4 + l];
     if (l == 4) created[dst] = created[src];
@@ -463,7 +501,7 @@ __global__ void move_row_kernel(float* emb32, double* emb64, uint16_t* emb16, in
 
 // batched swap-delete (lbh_index_retract_many): pair p copies row pairs[2p+1] (a survivor from the tail that is cut
 // off) over row pairs[2p] (a hole below the new end).  Sources and destinations are disjoint, so pairs are independent.
-__global__ void move_rows_kernel(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
+__global__ void move_rows_kernel(float* emb32, double* emb64, uint16_t* emb16, int8_t* emb8, int64_t* created, uint64_t* tags, uint64_t* keys,
                                  uint64_t* order, uint64_t* ids, const int64_t* __restrict__ pairs, int64_t n_pairs) {
     const int l = threadIdx.x & 63;
     const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -471,6 +509,7 @@ __global__ void move_rows_kernel(float* emb32, double* emb64, uint16_t* emb16, i
     const int64_t dst = pairs[2 * p], src = pairs[2 * p + 1];
     emb32[dst * 64 + l] = emb32[src * 64 + l];
     if (emb16) emb16[lbh_emb16_off(dst, l)] = emb16[lbh_emb16_off(src, l)];
+    if (emb8) emb8[lbh_emb8_off(dst, l)] = emb8[lbh_emb8_off(src, l)];
     emb64[dst * 64 + l] = emb64[src * 64 + l];
     if (l < 4) keys[dst * 4 + l] = keys[src * 4 + l];
     if (l == 4) created[dst] = created[src];
@@ -530,16 +569,33 @@ hipError_t lbh_launch_f64_to_f32(const double* in_dev, float* out_dev, int64_t n
     return hipGetLastError();
 }
 
-hipError_t lbh_launch_move_row(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
+hipError_t lbh_launch_move_row(float* emb32, double* emb64, uint16_t* emb16, int8_t* emb8, int64_t* created, uint64_t* tags, uint64_t* keys,
                                uint64_t* order, uint64_t* ids, int64_t dst, int64_t src, hipStream_t s) {
-    move_row_kernel<<<1, 64, 0, s>>>(emb32, emb64, emb16, created, tags, keys, order, ids, dst, src);
+    move_row_kernel<<<1, 64, 0, s>>>(emb32, emb64, emb16, emb8, created, tags, keys, order, ids, dst, src);
     return hipGetLastError();
 }
 
-hipError_t lbh_launch_move_rows(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
+hipError_t lbh_launch_move_rows(float* emb32, double* emb64, uint16_t* emb16, int8_t* emb8, int64_t* created, uint64_t* tags, uint64_t* keys,
                                 uint64_t* order, uint64_t* ids, const int64_t* pairs_dev, int64_t n_pairs, hipStream_t s) {
     if (n_pairs <= 0) return hipSuccess;
-    move_rows_kernel<<<dim3((unsigned)((n_pairs + 3) / 4)), 256, 0, s>>>(emb32, emb64, emb16, created, tags, keys, order, ids, pairs_dev, n_pairs);
+    move_rows_kernel<<<dim3((unsigned)((n_pairs + 3) / 4)), 256, 0, s>>>(emb32, emb64, emb16, emb8, created, tags, keys, order, ids, pairs_dev, n_pairs);
+    return hipGetLastError();
+}
+
+hipError_t lbh_launch_absmax_f64(const double* emb64_dev, int64_t row0, int64_t row1, uint32_t* out_bits_dev, hipStream_t s) {
+    if (row1 <= row0) return hipSuccess;
+    const int64_t e0 = row0 * 64, e1 = row1 * 64;
+    int64_t blocks = (e1 - e0 + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 4096) blocks = 4096;
+    absmax_f64_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(emb64_dev, e0, e1, out_bits_dev);
+    return hipGetLastError();
+}
+
+hipError_t lbh_launch_f64_to_i8_tiled(const double* emb64_dev, int8_t* emb8_dev, int64_t row0, int64_t row1, double inv_scale, hipStream_t s) {
+    if (row1 <= row0) return hipSuccess;
+    int64_t blocks = ((row1 - row0) * 4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    f64_to_i8_tiled_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(emb64_dev, emb8_dev, row0, row1, inv_scale);
     return hipGetLastError();
 }
 

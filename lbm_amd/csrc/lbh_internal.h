@@ -60,6 +60,22 @@ __host__ __device__ inline int64_t lbh_emb16_off(int64_t row, int d) {  // offse
     return (row >> 5) * 2048 + (int64_t)(d >> 4) * 512 + (int64_t)((((d >> 3) & 1) << 5) + (row & 31)) * 8 + (d & 7);
 }
 
+// ---- int8 copy of the claim matrix (emb8): the operand of the int8 batched scan (bq_mode 3) ----------------------------
+// x_i ~ scale * X_i with ONE scale for the whole index (|x_i| <= 127 scale for every element of every row) and X_i =
+// rint(x_i / scale) in [-127, 127].  Stored in the fragment order of v_mfma_i32_32x32x32_i8: a tile = 32 rows = 2 KiB =
+// two 1-KiB chunks, one per k-step s; chunk s holds, for lane L = 32 h + j, the 16 bytes dims 32 s + 16 h .. + 15 of row
+// 32 t + j at byte 16 L.  (The queries' B fragments use the same (lane, byte) -> dim map, so whatever order the matrix
+// core takes the 16 bytes of a lane in, both operands agree on it.)
+__host__ __device__ inline int64_t lbh_emb8_off(int64_t row, int d) {  // offset in bytes of element (row, d)
+    return (((row >> 5) * 2 + (int64_t)(d >> 5)) * 64 + (int64_t)((((d >> 4) & 1) << 5) + (row & 31))) * 16 + (d & 15);
+}
+// Error bound of one int8 score: x_i = s X_i + e_i, |e_i| <= s/2; q_i = t Q_i + f_i, |f_i| <= t/2, so
+// |x.q - s t sum X_i Q_i| <= (s/2)(|q|_1 + 32 t) + (t/2)(|x|_1 + 32 s) + 16 s t, with |x|_1 <= 8 |x|_2.
+__host__ __device__ inline float lbh_next_up(float f) {  // the next float above a non-negative finite f
+    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, f) + 1u);
+}
+#define LBH_I8_MARGIN_MAX 0.09f                 // a looser bound than this (odd data: one huge component) takes the fp16 kernel
+
 // ---- device arrays of one index (all row-major, row r at the natural offset) ------------------
 struct lbh_dev_index {
     const float* emb32;       // n x 64 fp32   (256 B rows)  -- the scan copy
@@ -149,7 +165,8 @@ struct lbh_workspace {
     uint64_t* bq_cand;        // 256 x LBH_BQ_PERQ flat candidate lists, one per query
     int32_t* bq_total;        // 256 counters, LBH_BQ_QT_STRIDE ints apart
     uint32_t* bq_seed;        // 256 per-query seed thresholds (ord32) from the sample pass
-    void* bq_bfrag;           // 32 KiB: the queries as fp16 MFMA B fragments (scan_batched_tiled_kernel)
+    void* bq_bfrag;           // 32 KiB: the queries as fp16 (or int8: 16 KiB) MFMA B fragments (scan_batched_tiled_kernel)
+    float* bq_qscale;         // 256: int8 mode, score of one integer unit of query q (emb8 scale x the query's own scale)
     lbh_result* bq_result_host;  // 256 results, pinned + device-mapped
     double* bq_qhost;            // 256 x 64 fp64 queries, pinned + device-mapped (read by the fp16 mode's first kernel)
     double* bq_qhost_dev;
@@ -180,10 +197,13 @@ hipError_t lbh_launch_embed(const uint8_t* utf8_dev, const int64_t* offsets_dev,
                             float* out32_dev, hipStream_t s, int dim = LBH_DIM, const lbh_memo* memo = nullptr);
 hipError_t lbh_launch_cosine(const double* a_dev, const double* b_dev, int64_t n, double* out_dev, hipStream_t s);
 hipError_t lbh_launch_f64_to_f32(const double* in_dev, float* out_dev, int64_t n_elems, hipStream_t s);
-hipError_t lbh_launch_move_row(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
+hipError_t lbh_launch_move_row(float* emb32, double* emb64, uint16_t* emb16, int8_t* emb8, int64_t* created, uint64_t* tags, uint64_t* keys,
                                uint64_t* order, uint64_t* ids, int64_t dst, int64_t src, hipStream_t s);
-hipError_t lbh_launch_move_rows(float* emb32, double* emb64, uint16_t* emb16, int64_t* created, uint64_t* tags, uint64_t* keys,
+hipError_t lbh_launch_move_rows(float* emb32, double* emb64, uint16_t* emb16, int8_t* emb8, int64_t* created, uint64_t* tags, uint64_t* keys,
                                 uint64_t* order, uint64_t* ids, const int64_t* pairs_dev, int64_t n_pairs, hipStream_t s);
+// int8 copy: largest |element| of rows [row0, row1) as float bits, raised into *out_bits_dev by atomicMax; then the conversion
+hipError_t lbh_launch_absmax_f64(const double* emb64_dev, int64_t row0, int64_t row1, uint32_t* out_bits_dev, hipStream_t s);
+hipError_t lbh_launch_f64_to_i8_tiled(const double* emb64_dev, int8_t* emb8_dev, int64_t row0, int64_t row1, double inv_scale, hipStream_t s);
 hipError_t lbh_launch_gather_rows_f64(const double* emb64, const int64_t* rows_dev, int64_t n, double* out_dev, hipStream_t s);
 hipError_t lbh_launch_f64_to_f16_tiled(const double* emb64_dev, uint16_t* emb16_dev, int64_t row0, int64_t row1, hipStream_t s);
 hipError_t lbh_launch_iota_u64(uint64_t* dst, uint64_t first, int64_t n, hipStream_t s);
@@ -210,9 +230,12 @@ hipError_t lbh_launch_recent(const int64_t* created, const uint64_t* order, int6
 // emb16: NULL, or the fp16 copy of the matrix as operand source of the fp16 mode (bf16 == 2)
 // q_src: where the kernels read the fp64 queries from -- ws.bq_qmat (already copied), or device-mapped host memory (fp16 mode
 // only: its first kernel then leaves the device copy in ws.bq_qmat); seq: completion ticket written into every query's result
+// bf16 == 3: the int8 mode -- emb8 / emb8_scale: the int8 copy and its scale, margin_i8: the candidate margin the caller
+// derived from the error bound for THESE queries (absolute, not multiplied by norm_scale)
 hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, const double* q_src, int nq,
                                      int k, int has_since, int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, float norm_scale,
-                                     int seq, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+                                     int seq, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const int8_t* emb8 = nullptr,
+                                     float emb8_scale = 0.f, float margin_i8 = 0.f);
 
 // allocation-free search: per-device address of the file-scope scratch array, and the launch sequence on it
 hipError_t lbh_noalloc_init(void** out_ptr);

@@ -1821,8 +1821,61 @@ constexpr int K3M_WAVES = K3M_THREADS / 64;
 
 // B operand image: [group g][k-step s][lane] x 16 B = dims 16 s + 8 h .. + 7 of query 32 g + j as fp16 (one rounding
 // from the fp64 query); queries >= nq are zero
+//
+// I8 (bq_mode 3): the queries as int8 B fragments of v_mfma_i32_32x32x32_i8 -- [group g][k-step s][lane] x 16 B = dims
+// 32 s + 16 h .. + 15 of query 32 g + j as Q_i = rint(q_i / t_q), t_q = (largest |q_i|) / 127 rounded up (1 for a zero
+// query) -- and qscale[q] = emb_scale * t_q, the score one integer unit of the product stands for.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+template <bool I8>
 __global__ void prep_bfrag_kernel(const double* __restrict__ qmat, int nq, f16x8* __restrict__ bfrag, int32_t* __restrict__ qtotal,
-                                  int32_t* __restrict__ flags, double* __restrict__ qcopy) {
+                                  int32_t* __restrict__ flags, double* __restrict__ qcopy, float* __restrict__ qscale, float emb_scale) {
+    if (I8) {
+        __shared__ uint32_t qmaxb[32];
+        const int t = threadIdx.x, jq = t & 31, part = t >> 5, q = 32 * blockIdx.x + jq;
+        if (t < 32) qmaxb[t] = 0u;
+        __syncthreads();
+        float m = 0.f;
+        if (q < nq) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const double a = __builtin_fabs(qmat[(size_t)q * 64 + 8 * part + e]);
+                float f = (float)a;
+                if ((double)f < a) f = lbh_next_up(f);
+                m = f > m ? f : m;
+            }
+        }
+        if (m > 0.f) atomicMax(&qmaxb[jq], __builtin_bit_cast(uint32_t, m));
+        __syncthreads();
+        const float qm = __builtin_bit_cast(float, qmaxb[jq]);
+        const float tq = qm > 0.f ? lbh_next_up(qm / 127.0f) : 1.0f;
+        if (part == 0 && q < BQ_MAXQ) qscale[q] = emb_scale * tq;
+        if (blockIdx.x == 0) {
+            qtotal[threadIdx.x * BQ_QT] = 0;
+            if (threadIdx.x < 4) flags[threadIdx.x] = 0;
+        }
+        if (qcopy) {
+            const int tt = blockIdx.x * 256 + threadIdx.x;
+            if (tt * 8 < nq * 64) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qcopy[tt * 8 + e] = qmat[tt * 8 + e];
+            }
+        }
+        if (t < 128) {  // (s, lane): 16 dims each
+            const int lane = t & 63, ks = t >> 6, j = lane & 31, h = lane >> 5, qq = 32 * blockIdx.x + j;
+            const float qm2 = __builtin_bit_cast(float, qmaxb[j]);
+            const double inv = qm2 > 0.f ? 1.0 / (double)lbh_next_up(qm2 / 127.0f) : 1.0;
+            union { int8_t b[16]; i32x4 v; } u;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int qi = qq < nq ? __double2int_rn(qmat[(size_t)qq * 64 + 32 * ks + 16 * h + e] * inv) : 0;
+                qi = qi > 127 ? 127 : (qi < -127 ? -127 : qi);
+                u.b[e] = (int8_t)qi;
+            }
+            reinterpret_cast<i32x4*>(bfrag)[(blockIdx.x * 2 + ks) * 64 + lane] = u.v;
+        }
+        return;
+    }
     if (blockIdx.x == 0) {  // first kernel of a batched search: also clears the per-query counters (no memset launches)
         qtotal[threadIdx.x * BQ_QT] = 0;
         if (threadIdx.x < 4) flags[threadIdx.x] = 0;
@@ -1867,7 +1920,7 @@ __device__ __forceinline__
 #else
 __device__ __noinline__
 #endif
-int k3t_harvest(f32x16 acc, float thr, bool lanehit, int q, int64_t row0, int64_t n,
+int k3t_harvest(f32x16 acc, float thr, float scale, bool lanehit, int q, int64_t row0, int64_t n,
                                         const int64_t* __restrict__ created, const uint64_t* __restrict__ tags,
                                         int has_since, int64_t since_ms, uint64_t tag_mask, uint64_t* se, uint16_t* sq, int cnt,
                                         uint64_t* __restrict__ cand3, int32_t* __restrict__ qtotal) {
@@ -1911,7 +1964,7 @@ int k3t_harvest(f32x16 acc, float thr, bool lanehit, int q, int64_t row0, int64_
         }
         if (pass) {
             const int pos = cnt + __popcll(pm & lt_mask);
-            se[pos] = ((uint64_t)lbh_ord32(acc[r]) << 32) | (uint32_t)(row0 + rowbit);
+            se[pos] = ((uint64_t)lbh_ord32(acc[r] * scale) << 32) | (uint32_t)(row0 + rowbit);  // scale: 1 (fp16 scores), or the score of one integer unit (int8)
             sq[pos] = (uint16_t)q;
         }
         cnt += __popcll(pm);
@@ -1942,14 +1995,26 @@ int k3t_harvest(f32x16 acc, float thr, bool lanehit, int q, int64_t row0, int64_
 #else
 #define K3T_LDSB ldsb
 #endif
+// I8 (bq_mode 3): the same kernel over the int8 copy -- a tile is 2 KiB = two k-steps of v_mfma_i32_32x32x32_i8 (half the
+// bytes, half the matrix cycles, 64 VGPRs of B fragments instead of 128, so three tiles are in flight); products and sums
+// are exact integers, compared in integer units against thresholds converted once per launch (one unit low, to be safe),
+// and a hit is listed with its score in real units (units x qscale[q]).
+#ifndef K3I_RING
+#define K3I_RING 3
+#endif
+template <bool I8>
 __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kernel(
     lbh_dev_index ix, const f32x4* __restrict__ emb16t, const f32x4* __restrict__ bfrag, int nq, int has_since, int64_t since_ms,
     uint64_t tag_mask, int64_t n_tiles, int64_t n_sel, uint64_t step_q32, const uint32_t* __restrict__ seed,
-    uint64_t* __restrict__ cand3, int32_t* __restrict__ qtotal) {
+    uint64_t* __restrict__ cand3, int32_t* __restrict__ qtotal, const float* __restrict__ qscale) {
+    constexpr int KS = I8 ? 2 : 4;            // k-steps (16-byte loads per lane) of a tile
+    constexpr int TILE_V = KS * 64;           // 16-byte chunks of a tile
+    constexpr int RING = I8 ? K3I_RING : K3T_RING;
 #if !K3T_BREG
     __shared__ f32x4 ldsb[8 * 4 * 64];  // [group][k-step][lane] x 16 B
 #endif
     __shared__ float ldsthr[BQ_MAXQ];
+    __shared__ float ldsscale[I8 ? BQ_MAXQ : 1];
     __shared__ uint64_t stage_e[K3T_WAVES][K3T_STAGE];
     __shared__ uint16_t stage_q[K3T_WAVES][K3T_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1965,7 +2030,13 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
 #endif
     for (int q = tid; q < BQ_MAXQ; q += K3T_THREADS) {
         const uint32_t o = (seed && q < nq) ? seed[q] : 0u;
-        ldsthr[q] = q < nq ? (o ? lbh_unord32(o) : -__builtin_inff()) : __builtin_inff();
+        float t = q < nq ? (o ? lbh_unord32(o) : -__builtin_inff()) : __builtin_inff();
+        if (I8) {
+            const float sc = qscale[q];
+            ldsscale[q] = sc;
+            if (q < nq && o) t = t / sc - 1.0f;  // integer units, one unit low: rounding here must never raise a threshold
+        }
+        ldsthr[q] = t;
 #ifdef K3T_NOHIT  // timing-only build: no row ever reaches a threshold (what the scan costs without the harvest path)
         ldsthr[q] = __builtin_inff();
 #endif
@@ -1978,30 +2049,53 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
         const int64_t t = (int64_t)(((unsigned __int128)(uint64_t)i * step_q32) >> 32);
         return t < n_tiles ? t : n_tiles - 1;
     };
-    auto load_tile = [&](f32x4 (&a)[4], int64_t i) {  // always issued (index clamped): no load under a lane-dependent guard
+    auto load_tile = [&](f32x4 (&a)[KS], int64_t i) {  // always issued (index clamped): no load under a lane-dependent guard
         int64_t t = tile_of(i < n_sel ? i : n_sel - 1);
 #ifdef K3T_L2WINDOW  // timing-only build: every tile comes from a 1 MiB, cache-resident window (what the scan costs without HBM)
         t &= 255;
 #endif
-        const f32x4* p = emb16t + t * 256 + lane;
+        const f32x4* p = emb16t + t * TILE_V + lane;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a[s] = __builtin_nontemporal_load(p + s * 64);
+        for (int s = 0; s < KS; ++s) a[s] = __builtin_nontemporal_load(p + s * 64);
     };
-    auto load_b_lds = [&](f32x4 (&b)[4], int g) {  // K3T_BREG: once per launch, straight from the global image
+    auto load_b_lds = [&](f32x4 (&b)[KS], int g) {  // K3T_BREG: once per launch, straight from the global image
 #pragma unroll
-        for (int s = 0; s < 4; ++s) b[s] = K3T_BREG ? bfrag[(g * 4 + s) * 64 + lane] : K3T_LDSB[(g * 4 + s) * 64 + lane];
+        for (int s = 0; s < KS; ++s) b[s] = K3T_BREG ? bfrag[(g * KS + s) * 64 + lane] : K3T_LDSB[(g * KS + s) * 64 + lane];
     };
-    [[maybe_unused]] auto load_b = [&](f32x4 (&b)[4], int g) {
+    [[maybe_unused]] auto load_b = [&](f32x4 (&b)[KS], int g) {
 #ifndef K3T_NOBREAD  // timing-only build: the B fragments are read once (what the scan costs without the LDS traffic)
         load_b_lds(b, g);
 #endif
     };
     // one 32 x 32 block: 4 MFMAs, lane maximum as a 3-level tree of v_max3_f32, one compare, one wave vote
-    auto block = [&](const f32x4 (&araw)[4], const f32x4 (&braw)[4], int g, int64_t row0) {
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto block = [&](const f32x4 (&araw)[KS], const f32x4 (&braw)[KS], int g, int64_t row0) {
+        if constexpr (I8) {
+            i32x16 ai = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < KS; ++s)
+                ai = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, araw[s]), __builtin_bit_cast(i32x4, braw[s]), ai, 0, 0, 0);
+            const float thr = ldsthr[g * 32 + j];
+            auto mx3 = [](int a, int b, int c) { const int t = a > b ? a : b; return t > c ? t : c; };
+            const int m0 = mx3(ai[0], ai[1], ai[2]), m1 = mx3(ai[3], ai[4], ai[5]), m2 = mx3(ai[6], ai[7], ai[8]);
+            const int m3 = mx3(ai[9], ai[10], ai[11]), m4 = mx3(ai[12], ai[13], ai[14]);
+            const int m5 = mx3(m0, m1, m2), m6 = mx3(m3, m4, ai[15]);
+            const float mx = (float)(m5 > m6 ? m5 : m6);  // |sum| <= 64 x 127 x 127 < 2^24: exact
+            const bool lanehit = mx >= thr;
+            if (__any(lanehit)) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = (float)ai[r];
+                cnt = k3t_harvest(acc, thr, ldsscale[g * 32 + j], lanehit, 32 * g + j, row0, n, ix.created, ix.tags, has_since, since_ms, tag_mask,
+                                  se, sq, cnt, cand3, qtotal);
+            }
+            return;
+        }
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (!I8) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, araw[s]), __builtin_bit_cast(f16x8, braw[s]), acc, 0, 0, 0);
+        }
         const float thr = ldsthr[g * 32 + j];
         // (v_max3_f32 through inline asm would save the two quieting v_max(x, x) the compiler adds, but the hazard
         // recogniser does not see an asm operand as a reader of MFMA results: it dropped the wait states and rows were missed)
@@ -2020,7 +2114,7 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
 #endif
         const bool lanehit = mx >= thr;
         if (__any(lanehit))  // rare: some query of this group has a row at or above its threshold
-            cnt = k3t_harvest(acc, thr, lanehit, 32 * g + j, row0, n, ix.created, ix.tags, has_since, since_ms, tag_mask, se, sq,
+            cnt = k3t_harvest(acc, thr, 1.0f, lanehit, 32 * g + j, row0, n, ix.created, ix.tags, has_since, since_ms, tag_mask, se, sq,
                               cnt, cand3, qtotal);
     };
 
@@ -2030,22 +2124,22 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
     // one tile against every query group; the next group's B fragments are read from LDS while this group's MFMAs run
     // (two register sets, ping-pong; after the last group the prefetch wraps to group 0 for the next tile)
 #if K3T_BREG  // experiment: all eight groups' B fragments in registers (128 VGPRs), two waves per SIMD, no LDS reads in the loop
-    f32x4 breg[8][4];
+    f32x4 breg[8][KS];
 #pragma unroll
     for (int g = 0; g < 8; ++g) load_b_lds(breg[g], g < ngroups ? g : 0);
-    auto process = [&](const f32x4 (&araw)[4], int64_t i) {
+    auto process = [&](const f32x4 (&araw)[KS], int64_t i) {
         const int64_t row0 = tile_of(i) * 32;
 #pragma unroll
         for (int g = 0; g < 8; ++g)
             if (g < ngroups) block(araw, breg[g], g, row0);  // wave-uniform
     };
 #else
-    f32x4 b0[4], b1[4];
+    f32x4 b0[KS], b1[KS];
     load_b_lds(b0, 0);
 #ifdef K3T_NOBREAD
     load_b_lds(b1, 0);
 #endif
-    auto process = [&](const f32x4 (&araw)[4], int64_t i) {
+    auto process = [&](const f32x4 (&araw)[KS], int64_t i) {
         const int64_t row0 = tile_of(i) * 32;
         for (int g = 0; g < ngroups; g += 2) {
             load_b(b1, g + 1 < ngroups ? g + 1 : 0);
@@ -2055,7 +2149,7 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
                 block(araw, b1, g + 1, row0);
             } else {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) b0[s] = b1[s];  // odd group count: b1 already holds group 0
+                for (int s = 0; s < KS; ++s) b0[s] = b1[s];  // odd group count: b1 already holds group 0
             }
         }
     };
@@ -2063,14 +2157,14 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
 
     // K3T_RING claim tiles in flight per wave.  The ring loop is fully unrolled, so every register set has a static name
     // (rotating the sets with register moves would make each move wait for the youngest load).
-    f32x4 ring[K3T_RING][4];
+    f32x4 ring[RING][KS];
 #pragma unroll
-    for (int r = 0; r < K3T_RING - 1; ++r) load_tile(ring[r], i0 + r * W);
-    for (int64_t i = i0; i < n_sel; i += K3T_RING * W) {
+    for (int r = 0; r < RING - 1; ++r) load_tile(ring[r], i0 + r * W);
+    for (int64_t i = i0; i < n_sel; i += RING * W) {
 #pragma unroll
-        for (int r = 0; r < K3T_RING; ++r) {
+        for (int r = 0; r < RING; ++r) {
             if (i + r * W < n_sel) {  // wave-uniform
-                load_tile(ring[(r + K3T_RING - 1) % K3T_RING], i + (r + K3T_RING - 1) * W);
+                load_tile(ring[(r + RING - 1) % RING], i + (r + RING - 1) * W);
                 process(ring[r], i + r * W);
             }
         }
@@ -2085,10 +2179,13 @@ __global__ __launch_bounds__(K3T_THREADS, K3T_WPS) void scan_batched_tiled_kerne
 // and the workgroup writes ONE value per query -- slot blockIdx.x of the query's list, in the list's entry format, 0 when
 // no row of the group passes the filters -- for seed_batched_kernel to pick the k-th largest of.  Scores come out of the
 // same instruction sequence on the same operands as in the full pass, hence bit-identical.
+template <bool I8>
 __global__ __launch_bounds__(K3M_THREADS, K3M_WPS) void scan_batched_max_kernel(
     lbh_dev_index ix, const f32x4* __restrict__ emb16t, const f32x4* __restrict__ bfrag, int nq, int has_since, int64_t since_ms,
-    uint64_t tag_mask, int64_t n_tiles, int64_t n_sel, uint64_t step_q32, uint64_t* __restrict__ cand3) {
-    __shared__ f32x4 ldsb[8 * 4 * 64];
+    uint64_t tag_mask, int64_t n_tiles, int64_t n_sel, uint64_t step_q32, uint64_t* __restrict__ cand3, const float* __restrict__ qscale) {
+    constexpr int KS = I8 ? 2 : 4;
+    constexpr int TILE_V = KS * 64;
+    __shared__ f32x4 ldsb[8 * KS * 64];
     __shared__ uint32_t blkmax[BQ_MAXQ];
     __shared__ float wmax[K3M_WAVES][8 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2096,34 +2193,43 @@ __global__ __launch_bounds__(K3M_THREADS, K3M_WPS) void scan_batched_max_kernel(
     const int ngroups = (nq + 31) >> 5;
     const int64_t n = ix.n;
     const bool filtered = has_since || tag_mask;
-    for (int i = tid; i < ngroups * 256; i += K3M_THREADS) ldsb[i] = bfrag[i];
+    for (int i = tid; i < ngroups * TILE_V; i += K3M_THREADS) ldsb[i] = bfrag[i];
     for (int q = tid; q < BQ_MAXQ; q += K3M_THREADS) blkmax[q] = 0u;
     __syncthreads();
     auto tile_of = [&](int64_t i) -> int64_t {
         const int64_t t = (int64_t)(((unsigned __int128)(uint64_t)i * step_q32) >> 32);
         return t < n_tiles ? t : n_tiles - 1;
     };
-    auto load_tile = [&](f32x4 (&a)[4], int64_t i) {
+    auto load_tile = [&](f32x4 (&a)[KS], int64_t i) {
         const int64_t t = tile_of(i < n_sel ? i : n_sel - 1);
-        const f32x4* p = emb16t + t * 256 + lane;
+        const f32x4* p = emb16t + t * TILE_V + lane;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a[s] = __builtin_nontemporal_load(p + s * 64);
+        for (int s = 0; s < KS; ++s) a[s] = __builtin_nontemporal_load(p + s * 64);
     };
     // running maxima: one LDS word per (query group, lane), private to the wave (registers would need a fully unrolled
     // group loop, and the compiler then hoists all 8 groups' B fragments: 266 spilled registers)
     float* gmax = wmax[wave];
     for (int g = 0; g < 8; ++g) gmax[g * 64 + lane] = -__builtin_inff();
-    auto load_b = [&](f32x4 (&b)[4], int g) {
+    auto load_b = [&](f32x4 (&b)[KS], int g) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) b[s] = ldsb[(g * 4 + s) * 64 + lane];
+        for (int s = 0; s < KS; ++s) b[s] = ldsb[(g * KS + s) * 64 + lane];
     };
     uint32_t rmask = 0xFFFFFFFFu;
     bool masked = false;
-    auto block = [&](const f32x4 (&araw)[4], const f32x4 (&braw)[4], int g) {
+    auto block = [&](const f32x4 (&araw)[KS], const f32x4 (&braw)[KS], int g) {
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (I8) {  // exact integer sums, kept as floats in integer units (< 2^24: exact); real scores at the end
+            i32x16 ai = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, araw[s]), __builtin_bit_cast(f16x8, braw[s]), acc, 0, 0, 0);
+            for (int s = 0; s < KS; ++s)
+                ai = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, araw[s]), __builtin_bit_cast(i32x4, braw[s]), ai, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = (float)ai[r];
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, araw[s]), __builtin_bit_cast(f16x8, braw[s]), acc, 0, 0, 0);
+        }
         if (masked) {  // wave-uniform: filters, or the index's last tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -2141,9 +2247,9 @@ __global__ __launch_bounds__(K3M_THREADS, K3M_WPS) void scan_batched_max_kernel(
         float* slot = &gmax[g * 64 + lane];
         *slot = __builtin_fmaxf(*slot, __builtin_fmaxf(m5, m6));
     };
-    f32x4 b0[4], b1[4];
+    f32x4 b0[KS], b1[KS];
     load_b(b0, 0);
-    auto process = [&](const f32x4 (&araw)[4], int64_t i) {
+    auto process = [&](const f32x4 (&araw)[KS], int64_t i) {
         const int64_t row0 = tile_of(i) * 32;
         masked = filtered || row0 + 32 > n;
         if (masked) {
@@ -2164,13 +2270,13 @@ __global__ __launch_bounds__(K3M_THREADS, K3M_WPS) void scan_batched_max_kernel(
                 block(araw, b1, g + 1);
             } else {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) b0[s] = b1[s];
+                for (int s = 0; s < KS; ++s) b0[s] = b1[s];
             }
         }
     };
     const int64_t W = (int64_t)gridDim.x * K3M_WAVES;
     const int64_t i0 = (int64_t)blockIdx.x * K3M_WAVES + wave;
-    f32x4 ring[2][4];
+    f32x4 ring[2][KS];
     load_tile(ring[0], i0);
     for (int64_t i = i0; i < n_sel; i += 2 * W) {
         load_tile(ring[1], i + W);
@@ -2182,7 +2288,8 @@ __global__ __launch_bounds__(K3M_THREADS, K3M_WPS) void scan_batched_max_kernel(
     }
     __builtin_amdgcn_wave_barrier();
     for (int g = 0; g < ngroups; ++g) {
-        const float m = __builtin_fmaxf(gmax[g * 64 + j], gmax[g * 64 + 32 + j]);
+        float m = __builtin_fmaxf(gmax[g * 64 + j], gmax[g * 64 + 32 + j]);
+        if (I8 && m > -__builtin_inff()) m = m * qscale[32 * g + j];  // integer units -> score, the multiplication the full pass's harvest does
         if (lane < 32 && m > -__builtin_inff()) atomicMax(&blkmax[32 * g + j], lbh_ord32(m));
     }
     __syncthreads();
@@ -2947,15 +3054,16 @@ hipError_t lbh_launch_search_noalloc(void* scratch_ptr, const lbh_dev_index& ix,
 }
 
 // K3, fp16: the pass schedule described above scan_batched_tiled_kernel.
-static hipError_t launch_batched_tiled(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, const double* q_src, int nq,
+template <bool I8>
+static hipError_t launch_batched_tiled(const lbh_dev_index& ix, const void* emb_tiled, const lbh_workspace& ws, const double* q_src, int nq,
                                        int k, int has_since, int64_t since_ms, uint64_t tag_mask, int n_cu, float margin, int seq,
-                                       hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+                                       hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, float emb_scale) {
     hipError_t e;
-    const f32x4* mat = reinterpret_cast<const f32x4*>(emb16);
+    const f32x4* mat = reinterpret_cast<const f32x4*>(emb_tiled);
     const f32x4* bfrag = reinterpret_cast<const f32x4*>(ws.bq_bfrag);
     // all 8 groups (unused ones as zeros); also clears the per-query counters and the flag words
-    prep_bfrag_kernel<<<8, 256, 0, s>>>(q_src, nq, reinterpret_cast<f16x8*>(ws.bq_bfrag), ws.bq_total, ws.flags,
-                                        q_src != ws.bq_qmat ? ws.bq_qmat : nullptr);
+    prep_bfrag_kernel<I8><<<8, 256, 0, s>>>(q_src, nq, reinterpret_cast<f16x8*>(ws.bq_bfrag), ws.bq_total, ws.flags,
+                                            q_src != ws.bq_qmat ? ws.bq_qmat : nullptr, ws.bq_qscale, emb_scale);
     const int64_t T = (ix.n + 31) / 32;
     auto step_of = [&](int64_t n_sel) -> uint64_t {
         // selected tile i = (i * T) / n_sel in 32.32 fixed point, rounded down so that it never passes T - 1
@@ -2964,8 +3072,8 @@ static hipError_t launch_batched_tiled(const lbh_dev_index& ix, const uint16_t* 
     auto launch = [&](int64_t n_sel, const uint32_t* seed) {
         int64_t blocks = (n_sel + K3T_WAVES - 1) / K3T_WAVES;
         if (blocks > K3T_BLOCKS_PER_CU * (int64_t)n_cu) blocks = K3T_BLOCKS_PER_CU * (int64_t)n_cu;
-        scan_batched_tiled_kernel<<<dim3((unsigned)blocks), K3T_THREADS, 0, s>>>(ix, mat, bfrag, nq, has_since, since_ms, tag_mask, T, n_sel,
-                                                                                step_of(n_sel), seed, ws.bq_cand, ws.bq_total);
+        scan_batched_tiled_kernel<I8><<<dim3((unsigned)blocks), K3T_THREADS, 0, s>>>(ix, mat, bfrag, nq, has_since, since_ms, tag_mask, T, n_sel,
+                                                                                    step_of(n_sel), seed, ws.bq_cand, ws.bq_total, ws.bq_qscale);
     };
     if (ev0) (void)hipEventRecord(ev0, s);
     const uint32_t* seed = nullptr;
@@ -2976,15 +3084,22 @@ static hipError_t launch_batched_tiled(const lbh_dev_index& ix, const uint16_t* 
         static const int div = [] {
             const char* ev = getenv("LBH_BQ_SAMPLE_DIV");
             const int v = ev ? atoi(ev) : 0;
-            return v >= 1 && v <= 4096 ? v : 14;
+            return v >= 1 && v <= 4096 ? v : 0;
         }();
-        int64_t n_sel = T / div;
+        // fp16: 14.  int8: the margin is ~15x wider, so a sample's k-th best lets more rows through; a denser sample pays
+        static const int div_i8 = [] {
+            const char* ev = getenv("LBH_BQ_SAMPLE_DIV_I8");
+            const int v = ev ? atoi(ev) : 0;
+            return v >= 1 && v <= 4096 ? v : 6;
+        }();
+        const int div_eff = div ? div : (I8 ? div_i8 : 14);
+        int64_t n_sel = T / div_eff;
         if (n_sel < 4096) n_sel = T < 4096 ? T : 4096;
         int64_t blocks = (n_sel + K3M_WAVES - 1) / K3M_WAVES;
         if (blocks > K3M_BLOCKS_PER_CU * (int64_t)n_cu) blocks = K3M_BLOCKS_PER_CU * (int64_t)n_cu;
         if (blocks > BQ_PERQ) blocks = BQ_PERQ;  // one list slot per workgroup
-        scan_batched_max_kernel<<<dim3((unsigned)blocks), K3M_THREADS, 0, s>>>(ix, mat, bfrag, nq, has_since, since_ms, tag_mask, T, n_sel,
-                                                                              step_of(n_sel), ws.bq_cand);
+        scan_batched_max_kernel<I8><<<dim3((unsigned)blocks), K3M_THREADS, 0, s>>>(ix, mat, bfrag, nq, has_since, since_ms, tag_mask, T, n_sel,
+                                                                                  step_of(n_sel), ws.bq_cand, ws.bq_qscale);
         seed_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(k, margin, ws.bq_cand, ws.bq_total, ws.bq_seed, (int)blocks);
         seed = ws.bq_seed;
     }
@@ -2998,7 +3113,8 @@ static hipError_t launch_batched_tiled(const lbh_dev_index& ix, const uint16_t* 
 
 hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* emb16, const lbh_workspace& ws, const double* q_src, int nq,
                                      int k, int has_since, int64_t since_ms, uint64_t tag_mask, int n_cu, int bf16, float norm_scale,
-                                     int seq, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+                                     int seq, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const int8_t* emb8, float emb8_scale,
+                                     float margin_i8) {
     // one-time set-up (thread-safe: searches on different indexes may arrive concurrently)
     static std::once_flag once;
     static hipError_t once_err = hipSuccess;
@@ -3029,8 +3145,11 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* em
     // the error bounds are relative to |x||q| (1 for the reference's unit vectors); fp16 additionally needs the
     // components inside its range, so anything but unit-scale data takes the split-bf16 kernel instead (the caller
     // passes the fp16 copy only for unit-scale data)
+    if (bf16 == 3 && emb8)
+        return launch_batched_tiled<true>(ix, emb8, ws, q_src, nq, k, has_since, since_ms, tag_mask, n_cu, margin_i8, seq, s, ev0, ev1, emb8_scale);
+    if (bf16 == 3) bf16 = 2;
     if (bf16 == 2 && (!emb16 || norm_scale > 1.001f || norm_scale < 0.25f)) bf16 = 1;
-    if (bf16 == 2) return launch_batched_tiled(ix, emb16, ws, q_src, nq, k, has_since, since_ms, tag_mask, n_cu, LBH_MARGIN_F16 * norm_scale, seq, s, ev0, ev1);
+    if (bf16 == 2) return launch_batched_tiled<false>(ix, emb16, ws, q_src, nq, k, has_since, since_ms, tag_mask, n_cu, LBH_MARGIN_F16 * norm_scale, seq, s, ev0, ev1, 0.f);
     const float margin = (bf16 ? LBH_MARGIN_BF16X3 : LBH_MARGIN) * norm_scale;
     e = hipMemsetAsync(ws.flags, 0, 16, s);
     if (e != hipSuccess) return e;

@@ -141,6 +141,35 @@ __global__ __launch_bounds__(1024) void kdual(float* out, int iters, float thr) 
     out[blockIdx.x * blockDim.x + threadIdx.x] = (float)hits;
 }
 
+// The same 32 x 32 x 64 block from TWO v_mfma_i32_32x32x32_i8 (int8 operands, 16 per lane and k-step; i32 accumulators) and an
+// integer 16-way maximum: half the matrix cycles of the fp16 block.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(1024) void ki8(float* out, int iters, float thr) {
+    unsigned x = 0x9E3779B9u * (threadIdx.x + 1) + 12345u * blockIdx.x;
+    i32x4 a[2], b[2];
+    for (int s = 0; s < 2; ++s)
+        for (int e = 0; e < 4; ++e) {
+            x = x * 1664525u + 1013904223u; a[s][e] = (int)x;
+            x = x * 1664525u + 1013904223u; b[s][e] = (int)x;
+        }
+    const int ithr = (int)thr;
+    int hits = 0;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll 1
+        for (int g = 0; g < 8; ++g) {
+            i32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[s], acc, 0, 0, 0);
+            int m = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = acc[r] > m ? acc[r] : m;
+            if (__any(m >= ithr)) ++hits;
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)hits;
+}
+
 template <class K>
 void run_k(const char* name, K kern, int threads, int blocks) {
     float* out;
@@ -186,6 +215,7 @@ int main() {
                 run_k("16x16x32 + max", k16<false>, threads, blocks);
                 run_k("16x16x32, 2 blocks ahead", k16<true>, threads, blocks);
             }
+            run_k("int8 2 x 32x32x32 + max", ki8, threads, blocks);  // (per fp16-MFMA equivalent: one block = 4 units)
         }
     }
     return 0;
