@@ -230,3 +230,52 @@ def test_cross_block_bound_for_large_k_is_exact(hip):
     finally:
         hip.set_option("scan_xb_k", 24)
         hip.set_option("force_exact", 0)
+
+
+def test_int8_copy_follows_appends_tombstones_and_a_change_of_scale(hip):
+    """bq_mode 3 keeps an int8 copy of the matrix (one scale for the index) next to the fp64 master: it must follow appended
+    rows, single and batched swap-deletes, and be quantised again when a new row's largest component exceeds the scale --
+    after every step the int8 batched search must equal the fp16 one (both are exact: same ids, same fp64 score bits)
+    and must have been served by the int8 kernel."""
+    rng = np.random.default_rng(11)
+
+    def unit(m):
+        v = rng.standard_normal((m, 64))
+        return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+    def keys(m):
+        return rng.integers(0, 256, size=(m, 32), dtype=np.uint8)
+
+    ix = hip.Index()
+    ids = ix.add_vectors(unit(30_000), np.arange(30_000, dtype=np.int64), None, keys(30_000))
+    qv = unit(9)
+    st = hip.Stats()
+
+    def check(tag):
+        hip.set_option("bq_mode", 3)
+        a = [x.copy() for x in ix.search(qv, 8, hip.SINCE_NONE, 0, st)]
+        assert st.path == 2 and st.bytes_per_row == 64 and 0.0 < st.margin < 0.09 and st.max_score_err < st.margin / 2, (tag, st.bytes_per_row, st.margin)
+        hip.set_option("bq_mode", 2)
+        b = ix.search(qv, 8, hip.SINCE_NONE, 0, st)
+        assert st.bytes_per_row == 128
+        assert a[0].tolist() == b[0].tolist() and a[1].tobytes() == b[1].tobytes() and a[2].tolist() == b[2].tolist(), tag
+
+    try:
+        check("built")
+        ids2 = ix.add_vectors(unit(5_000), np.arange(5_000, dtype=np.int64), None, keys(5_000))
+        check("appended")
+        ix.retract_many(np.concatenate([ids[100:4_000:3], ids2[::5]]))
+        check("batched swap-delete")
+        for i in (7, 29_999, 20_000):
+            ix.retract(int(ids[i]))
+        check("single swap-deletes")
+        spike = np.zeros((2, 64))
+        spike[0, 5] = 1.0  # a unit vector with ONE component: far above the scale the random rows set (~0.45 / 127)
+        spike[1, :2] = [0.8, -0.6]
+        ix.add_vectors(spike, np.zeros(2, dtype=np.int64), None, keys(2))
+        check("scale raised, copy quantised again")
+        ix.add_vectors(unit(3_000), np.zeros(3_000, dtype=np.int64), None, keys(3_000))
+        check("appended under the new scale")
+    finally:
+        hip.set_option("bq_mode", 2)
+        ix.close()
