@@ -2892,7 +2892,9 @@ hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const uint16_t* emb16
     // fuse: 0 never, 1 when the grid is one block per CU AND the index is small or medium (up to 4 M rows: there the
     // hand-off between two launches is a visible share of the query; beyond, e.g. the fp16 flavour's one-block grid
     // at 10 M rows, it buys < 1 % and the scan kernel keeps a duration of its own), 2 always
-    fuse = (fuse >= 2 || (fuse == 1 && grid <= n_cu && ix.n <= 4000000u)) && !xc && ws.bmax;
+    // (a claim-sharded search fuses too: the select step writes the rank's packed list either way, and the gated exact
+    // pass and the all-gather behind it are stream-ordered after this launch)
+    fuse = (fuse >= 2 || (fuse == 1 && grid <= n_cu && ix.n <= 4000000u)) && ws.bmax;
     // the fp16 flavour keeps the grid-stride loop: contiguous ranges cost it 2-3 % (10 M rows: 195 -> 198-201 us)
     const lbh_split sp = emb16 ? lbh_split{{0, 0, 0, 0}, 0} : lbh_scan_split(ix.n, grid, n_cu);
     if (ev0) (void)hipEventRecord(ev0, s);
