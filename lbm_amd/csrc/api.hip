@@ -1459,7 +1459,9 @@ int search_many(lbh_index* ix, lbh_slot* sl, const double* q_f64, int64_t nq, in
     // re-run below on the single-query path, so results never depend on which path served them.
     // top_k: the fp16 kernel keeps no per-query state in registers, so it serves any k of one result page (<= 64); the
     // fp32 / split-bf16 kernels keep k-entry lists per lane and stop at LBH_BQ_KMAX (larger k: single-query path below)
-    if (nq >= 3 && keff >= 1 && keff <= (ix->ctx->bq_mode >= 2 ? LBH_MAX_PAGE : LBH_BQ_KMAX) && ix->n > 0) {
+    // (round 3: the tiled kernels also serve top_k up to LBH_BQ_PAGED_KMAX -- the pass lists every row within the margin of
+    // a query's k-th best whatever k is, and the select step is run once per result page of LBH_MAX_PAGE rows)
+    if (nq >= 3 && keff >= 1 && keff <= (ix->ctx->bq_mode >= 2 ? LBH_BQ_PAGED_KMAX : LBH_BQ_KMAX) && ix->n > 0) {
         int rc = ensure_batched_ws(sl);
         if (rc) return rc;
         lbh_ctx* c = ix->ctx;
@@ -1497,6 +1499,7 @@ int search_many(lbh_index* ix, lbh_slot* sl, const double* q_f64, int64_t nq, in
             // the fp16 kernel streams the fp16 copy of the matrix (128 B/claim, MFMA-fragment order; built on first use)
             const bool src16 = !src8 && c->bq_mode >= 2 && nscale >= 0.25f && nscale <= 1.001f;
             if (!src8 && !src16 && keff > LBH_BQ_KMAX) continue;  // data outside fp16's range with a large k: single-query path
+            const float margin_used = src8 ? margin8 : LBH_MARGIN_F16 * nscale;  // (of the tiled kernels: what a further page's select needs)
             if (src16 && !emb16_current(ix)) return LBH_NEED_EMB16;
             any16 = any16 || src16;
             any8 = any8 || src8;
@@ -1523,21 +1526,33 @@ int search_many(lbh_index* ix, lbh_slot* sl, const double* q_f64, int64_t nq, in
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, sl->ev[0], sl->ev[1]) == hipSuccess) total.scan_ms += ms;
             }
-            for (int i = 0; i < nb; ++i) {
-                const lbh_result* r = sl->ws.bq_result_host + i;
-                if (r->overflow) continue;  // served by the single-query path below
-                const int64_t q = q0 + i;
-                for (int j = 0; j < r->count; ++j) {
-                    out_ids[q * k + j] = ix->id_of_row[r->rows[j]];
-                    out_scores[q * k + j] = r->scores[j];
-                    if (out_keys)
-                        for (int w = 0; w < 4; ++w) store_be64(out_keys + (q * k + j) * 32 + 8 * w, r->keys[j][w]);
+            std::vector<char> over((size_t)nb, 0);
+            for (int64_t off = 0; off < keff; off += LBH_MAX_PAGE) {
+                if (off > 0) {  // a further page of every query: the select step alone, on the lists the pass left
+                    const int32_t pseq = sl->seq = (sl->seq == INT32_MAX) ? 1 : sl->seq + 1;
+                    HIP_TRY(lbh_launch_select_batched_page(dv, sl->ws, nb, (int)keff, margin_used, pseq, (int)off, s));
+                    for (int i = 0; i < nb; ++i) HIP_TRY(wait_ticket(c, s, &sl->ws.bq_result_host[i].seq, pseq));
                 }
-                out_counts[q] = r->count;
-                total.candidates += r->candidates;
-                total.max_score_err = std::max(total.max_score_err, r->max_err);
-                done[(size_t)q] = 1;
+                for (int i = 0; i < nb; ++i) {
+                    const lbh_result* r = sl->ws.bq_result_host + i;
+                    if (r->overflow) over[(size_t)i] = 1;
+                    if (over[(size_t)i]) continue;  // served by the single-query path below
+                    const int64_t q = q0 + i;
+                    for (int j = 0; j < r->count; ++j) {
+                        out_ids[q * k + off + j] = ix->id_of_row[r->rows[j]];
+                        out_scores[q * k + off + j] = r->scores[j];
+                        if (out_keys)
+                            for (int w = 0; w < 4; ++w) store_be64(out_keys + (q * k + off + j) * 32 + 8 * w, r->keys[j][w]);
+                    }
+                    if (off == 0 || r->count > 0) out_counts[q] = off + r->count;  // (a page past the last result is empty)
+                    if (off == 0) {
+                        total.candidates += r->candidates;
+                        total.max_score_err = std::max(total.max_score_err, r->max_err);
+                    }
+                }
             }
+            for (int i = 0; i < nb; ++i)
+                if (!over[(size_t)i]) done[(size_t)(q0 + i)] = 1;
         }
         total.path = 2;
         total.bytes_per_row = (any8 ? 64 : any16 ? 128 : 256) + (has_since ? 8 : 0) + (tag_mask ? 8 : 0);

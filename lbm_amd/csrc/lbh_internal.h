@@ -237,6 +237,10 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* em
                                      int seq, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, const int8_t* emb8 = nullptr,
                                      float emb8_scale = 0.f, float margin_i8 = 0.f);
 
+hipError_t lbh_launch_select_batched_page(const lbh_dev_index& ix, const lbh_workspace& ws, int nq, int k, float margin, int seq,
+                                          int out_off, hipStream_t s);
+#define LBH_BQ_PAGED_KMAX 256                   // largest top_k the tiled batched kernels serve (in result pages of LBH_MAX_PAGE)
+
 // allocation-free search: per-device address of the file-scope scratch array, and the launch sequence on it
 hipError_t lbh_noalloc_init(void** out_ptr);
 hipError_t lbh_launch_search_noalloc(void* scratch_ptr, const lbh_dev_index& ix, const lbh_qarg& qa, int k, int has_since,

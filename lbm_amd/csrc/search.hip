@@ -930,7 +930,8 @@ __device__ uint64_t block_radix_select(int E, int nbytes, int64_t krem, F val, i
 template <int NT = SEL_THREADS>
 __device__ void rerank_and_emit(uint64_t* xo, uint32_t* xr, int M, int k, const lbh_dev_index& ix,
                                 const double* qs, lbh_result* __restrict__ res, bool have_scores, const lbh_xchg& xc,
-                                const uint32_t* scan_ord = nullptr) {  // scan_ord[i]: fp32 score image of row tid + i * NT
+                                const uint32_t* scan_ord = nullptr,   // scan_ord[i]: fp32 score image of row tid + i * NT
+                                int out_off = 0) {                    // result page: ranks [out_off, out_off + LBH_MAX_PAGE) of the top-k are written
     const int tid = threadIdx.x;
     const int n2 = pow2_at_least(M, 2);
     __shared__ uint32_t sh_err;  // largest |scan score - exact score| among the re-scored rows (float bits, >= 0)
@@ -958,7 +959,11 @@ __device__ void rerank_and_emit(uint64_t* xo, uint32_t* xr, int M, int k, const 
         sort_exact(xo, xr, n2, tid, NT, ix.keys, BlockSync());
     }
     K4_STAMP(4);  // sorted
-    const int cnt = M < k ? M : k;
+    const int cnt_all = M < k ? M : k;
+    int cnt = cnt_all - out_off;
+    cnt = cnt < 0 ? 0 : (cnt > LBH_MAX_PAGE ? LBH_MAX_PAGE : cnt);
+    xo += out_off;
+    xr += out_off;
     if (tid < cnt) {
         const uint32_t r = xr[tid];
         res->rows[tid] = r;
@@ -1085,13 +1090,14 @@ __device__ void select_small(const lbh_dev_index& ix, const double* qs, int k, c
 // `qs` (64 doubles in LDS) must be filled and a barrier passed before the call.
 template <int NT = SEL_THREADS>
 __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int k, const uint64_t* cand,
-                                 int E, lbh_result* __restrict__ res, float margin, const lbh_xchg& xc = lbh_xchg{nullptr, 0, 0}) {
+                                 int E, lbh_result* __restrict__ res, float margin, const lbh_xchg& xc = lbh_xchg{nullptr, 0, 0},
+                                 int out_off = 0) {
     __shared__ uint64_t sbuf[2 * LBH_MCAP];      // 32 KB: entries, later (ord64 | rows)
     __shared__ int hist[256];
     __shared__ int64_t sh_krem;
     __shared__ int sh_bin, sh_cnt;
     const int tid = threadIdx.x;
-    if (E <= 64) {  // block-uniform (one entry per lane; with two, 65-128 entries took longer than the block-wide path below)
+    if (E <= 64 && k <= LBH_MAX_PAGE && out_off == 0) {  // block-uniform (one entry per lane; with two, 65-128 entries took longer than the block-wide path below)
         select_small(ix, qs, k, cand, E, res, xc);
         return;
     }
@@ -1258,7 +1264,7 @@ __device__ void select_fast_body(const lbh_dev_index& ix, const double* qs, int 
     for (int i = 0; i < MPT; ++i)
         if (tid + i * NT < M) xr[tid + i * NT] = myrows[i];
     __syncthreads();
-    rerank_and_emit<NT>(xo, xr, M, k, ix, qs, res, false, xc, myord);
+    rerank_and_emit<NT>(xo, xr, M, k, ix, qs, res, false, xc, myord, out_off);
 }
 
 __device__ void fused_select(const lbh_dev_index& ix, const double* qs, int k, const uint64_t* cand, int E, lbh_result* res,
@@ -2332,7 +2338,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_batched_kernel(lbh_dev_ind
                                                                       int k, float margin, const uint64_t* __restrict__ cand3,
                                                                       const int32_t* __restrict__ qtotal,
                                                                       const int32_t* __restrict__ flags,
-                                                                      lbh_result* __restrict__ res_arr, int seq) {
+                                                                      lbh_result* __restrict__ res_arr, int seq, int out_off) {
     __shared__ double qs[64];
     const int tid = threadIdx.x, q = blockIdx.x;
     lbh_result* res = res_arr + q;
@@ -2346,7 +2352,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_batched_kernel(lbh_dev_ind
     }
     int E = raw;
     if (E > BQ_PERQ) E = BQ_PERQ;
-    select_fast_body(ix, qs, k, cand3 + (size_t)q * BQ_PERQ, E, res, margin);
+    select_fast_body(ix, qs, k, cand3 + (size_t)q * BQ_PERQ, E, res, margin, lbh_xchg{nullptr, 0, 0}, out_off);
     publish_result(res, seq);  // every query's block carries its own completion ticket (mapped host memory)
 }
 
@@ -3109,7 +3115,15 @@ static hipError_t launch_batched_tiled(const lbh_dev_index& ix, const void* emb_
     if (ev1) (void)hipEventRecord(ev1, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    select_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(ix, ws.bq_qmat, k, margin, ws.bq_cand, ws.bq_total, ws.flags, ws.bq_result_dev, seq);
+    select_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(ix, ws.bq_qmat, k, margin, ws.bq_cand, ws.bq_total, ws.flags, ws.bq_result_dev, seq, 0);
+    return hipGetLastError();
+}
+
+// a further result page of the batched search just run on `ws` (top_k > LBH_MAX_PAGE): the select step again, emitting
+// ranks [out_off, out_off + LBH_MAX_PAGE) of every query into its result block
+hipError_t lbh_launch_select_batched_page(const lbh_dev_index& ix, const lbh_workspace& ws, int nq, int k, float margin, int seq,
+                                          int out_off, hipStream_t s) {
+    select_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(ix, ws.bq_qmat, k, margin, ws.bq_cand, ws.bq_total, ws.flags, ws.bq_result_dev, seq, out_off);
     return hipGetLastError();
 }
 
@@ -3193,7 +3207,7 @@ hipError_t lbh_launch_search_batched(const lbh_dev_index& ix, const uint16_t* em
     if (ev1) (void)hipEventRecord(ev1, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    select_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(ix, ws.bq_qmat, k, margin, ws.bq_cand, ws.bq_total, ws.flags, ws.bq_result_dev, seq);
+    select_batched_kernel<<<nq, SEL_THREADS, 0, s>>>(ix, ws.bq_qmat, k, margin, ws.bq_cand, ws.bq_total, ws.flags, ws.bq_result_dev, seq, 0);
     return hipGetLastError();
 }
 
