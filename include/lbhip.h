@@ -165,8 +165,8 @@ int lbh_index_get_embeddings(lbh_index* idx, int64_t n, const uint64_t* ids, dou
  * Outputs, per query q: out_counts[q] results in out_ids[q*k ..] / out_scores[q*k ..], ordered
  * exactly like the reference: score descending, then hash key ascending.  Scores are the
  * reference's fp64 values bit-for-bit.  stats may be NULL.
- * Three or more queries with 1 <= k <= 64 (<= 16 unless the scan runs in its default fp16 mode on
- * unit-scale vectors) share ONE pass over the claim matrix on the matrix cores, 256 queries per
+ * Three or more queries with 1 <= k <= 256 (<= 16 unless the scan runs in its default fp16 mode on
+ * unit-scale vectors; above 64 the ranking step runs once per 64 results) share ONE pass over the claim matrix on the matrix cores, 256 queries per
  * launch; results do not depend on which path served a query. */
 int lbh_index_search(lbh_index* idx, const double* q_f64, int64_t nq, int64_t k, int64_t since_ms,
                      uint64_t tag_mask, uint64_t* out_ids, double* out_scores, int64_t* out_counts,
