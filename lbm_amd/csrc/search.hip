@@ -3088,7 +3088,7 @@ static hipError_t launch_batched_tiled(const lbh_dev_index& ix, const void* emb_
     if (ix.n > BQ_PERQ) {
         // SAMPLE pass over 1/div of the tiles (at least 4096 tiles, or all of them), then thresholds from the group maxima.
         // About k * div rows per query then reach their threshold in the full pass; the harvest path costs ~0.2 us of a
-        // wave's time per hit, the sample pass its share of a full pass, which puts the optimum near div = 14 at top-8.
+        // wave's time per hit, the sample pass its share of a full pass, which puts the optimum near div = 14 at top-8 (below).
         static const int div = [] {
             const char* ev = getenv("LBH_BQ_SAMPLE_DIV");
             const int v = ev ? atoi(ev) : 0;
@@ -3100,7 +3100,11 @@ static hipError_t launch_batched_tiled(const lbh_dev_index& ix, const void* emb_
             const int v = ev ? atoi(ev) : 0;
             return v >= 1 && v <= 4096 ? v : 6;
         }();
-        const int div_eff = div ? div : (I8 ? div_i8 : 14);
+        // the harvest path's cost grows with k x div, the sample pass's with 1 / div: the optimum moves as 1 / sqrt(k)
+        // (10 M x 256: k = 64, div 14 -> 5: 0.64 -> 0.60 ms; k = 200, 14 -> 3: 1.36 -> 1.05 ms)
+        int div_k = (int)(40.0 / __builtin_sqrt((double)(k < 1 ? 1 : k)) + 0.5);
+        div_k = div_k < 3 ? 3 : (div_k > 14 ? 14 : div_k);
+        const int div_eff = div ? div : (I8 ? div_i8 : div_k);
         int64_t n_sel = T / div_eff;
         if (n_sel < 4096) n_sel = T < 4096 ? T : 4096;
         int64_t blocks = (n_sel + K3M_WAVES - 1) / K3M_WAVES;
