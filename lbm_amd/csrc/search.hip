@@ -2881,6 +2881,8 @@ lbh_split lbh_scan_split(int64_t n_rows, int grid, int n_cu) {
     // first, odd XCDs ~10 % slower than even ones): 10 M claims 376-386 -> 374-376 us.  The end time barely moves with
     // the shares -- every variant, perfectly levelled ones included, ends at 368-373 us, i.e. at ~6.9 TB/s: that is the
     // rate this memory system sustains, not a balance problem.
+    // (constants from one box's block timelines; checked on three other GPUs in round 3: 1.3-2.7 % ahead of equal shares and
+    // of the grid-stride loop on each, profiles/r03_scan_split_three_boxes.txt)
     static const uint32_t one[4] = {1000, 1000, 1000, 1000}, two[4] = {1127, 1016, 977, 880};
     const uint32_t* w = g_split_set ? g_split_w : (grid > n_cu ? two : one);
     for (int i = 0; i < 4; ++i) sp.w[i] = w[i];
