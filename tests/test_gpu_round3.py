@@ -279,3 +279,32 @@ def test_int8_copy_follows_appends_tombstones_and_a_change_of_scale(hip):
     finally:
         hip.set_option("bq_mode", 2)
         ix.close()
+
+
+def test_select_flavours_agree_two_kernels_fused_and_fused_on_a_large_grid(hip):
+    """The single-query scan ends in one of three ways: its own select kernel (scan_fuse 0), the select step run by the
+    scan's last block (1, the default for small and medium indexes), and the same on a grid of more blocks than the last
+    block has threads (scan_fuse 2 with four blocks per CU: 1024 blocks, more than the 512 slots of the k-th-largest
+    bound).  All must return what the exact fp64 path returns."""
+    from lbm_amd import synth
+    ch = synth.make_chunk(0, 600_000, seed=41, real_sha_keys=False, dup_frac=0.02)
+    ix = hip.Index()
+    ix.add_texts(ch.blob, ch.offsets, ch.created_ms, ch.tagmask, ch.keys)
+    qv = hip.embed_batch(synth.make_queries(4, seed=9) + [ch.text(5), ""])
+    p90 = int(ch.created_ms[ch.n * 9 // 10])
+    cases = [(8, hip.SINCE_NONE, 0), (64, hip.SINCE_NONE, 0), (20, p90, 0), (8, hip.SINCE_NONE, 1 << 3), (64, p90, 0b101)]
+    try:
+        hip.set_option("force_exact", 1)
+        want = {(j, c): [a.copy() for a in ix.search_shard(qv[j], *c)] for j in range(len(qv)) for c in cases}
+        hip.set_option("force_exact", 0)
+        for fuse, bpc in ((0, 0), (1, 0), (2, 0), (2, 4), (0, 4)):
+            hip.set_option("scan_fuse", fuse)
+            hip.set_option("scan_blocks_per_cu", bpc)
+            for (j, c), w in want.items():
+                got = ix.search_shard(qv[j], *c)
+                assert got[0].tolist() == w[0].tolist() and got[1].tobytes() == w[1].tobytes() and got[2].tobytes() == w[2].tobytes(), (fuse, bpc, j, c)
+    finally:
+        hip.set_option("scan_fuse", 1)
+        hip.set_option("scan_blocks_per_cu", 0)
+        hip.set_option("force_exact", 0)
+        ix.close()
