@@ -16,6 +16,10 @@
 #include <shared_mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <atomic>
+#include <memory>
+#include <limits>
 #include <vector>
 
 #include "lbh_internal.h"
@@ -49,6 +53,9 @@ int fail(int code, const char* fmt, ...) {
 }  // namespace
 
 #define LBH_QUERY_ZERO_COPY_MAX 8192  // lbh_index_search_text: queries up to this many bytes are read by K1 straight from mapped host memory
+#define LBH_STAGE_NBUF 12                     // pinned pieces of the ingest staging ring
+#define LBH_STAGE_PIECE ((size_t)8 << 20)     // bytes per piece
+#define LBH_STAGE_HELPERS 8                   // most threads copying the caller's pageable buffers into the ring (option "stage_helpers")
 #define LBH_ADD_SLICES 4  // most slices one lbh_index_add call is cut into
 
 struct lbh_ctx {
@@ -56,6 +63,10 @@ struct lbh_ctx {
     int n_cu = 256;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;            // H2D copies of lbh_index_add's text slices (overlap with K1 on `stream`)
+    // staging ring of lbh_index_add for PAGEABLE caller buffers (StagedCopier): pinned pieces filled by helper threads
+    std::mutex stage_mu;
+    void* stage_buf[LBH_STAGE_NBUF] = {};
+    hipEvent_t stage_ev[LBH_STAGE_NBUF] = {};
     hipEvent_t copy_ev[LBH_ADD_SLICES + 1] = {};  // one per slice of text + one for the metadata columns
     std::string arch;
     int scan_blocks_per_cu = 0;  // tuning knobs (env LBH_SCAN_BLOCKS_PER_CU / LBH_SCAN_NT); 0 = by index size (lbh_scan_grid)
@@ -70,6 +81,7 @@ struct lbh_ctx {
     uint64_t* memo_table = nullptr;
     uint32_t memo_mask = 0;
     uint32_t memo_epoch = 0;       // launches that used the table so far (a launch trusts only entries of earlier ones)
+    int stage_helpers = 2; // option "stage_helpers": threads that copy pageable caller buffers into the pinned staging ring (1..8)
     int add_cuts = 0;      // option "add_cuts" (experiments): cuts of lbh_index_add's four text slices, a * 10000 + b * 100 + c sixteenths; 0 = built-in
     int scan_xb_k = 24;    // option "scan_xb_k": smallest top_k for which the scan's waves share a cross-block bound at their compactions (0 = never)
     int scan_fuse = 1;     // option "scan_fuse": the scan's last block runs the select step itself -- 0 never, 1 = when the grid is one block per CU (default), 2 always
@@ -240,9 +252,17 @@ int index_reserve_locked(lbh_index* ix, int64_t want) {
         ix->emb8_rows = ix->emb8_cap = 0;
     }
     try {  // the host-side id maps grow with the device columns, so that no ingest call pays a vector re-allocation
-        ix->id_of_row.reserve((size_t)want);
+        // ... nor the first-touch page faults of the reserved space (a million new ids = 4 000 faults = 2-3 ms of the call):
+        // the space is touched here, once, by growing and shrinking the vector
+        auto reserve_touched = [](auto& v, size_t cap) {
+            if (v.capacity() >= cap) return;
+            const size_t sz = v.size();
+            v.resize(cap);
+            v.resize(sz);
+        };
+        reserve_touched(ix->id_of_row, (size_t)want);
         if (ix->row_of_id.capacity() < ix->row_of_id.size() + (size_t)(want - ix->n))
-            ix->row_of_id.reserve(std::max(ix->row_of_id.size() + (size_t)(want - ix->n), 2 * ix->row_of_id.capacity()));
+            reserve_touched(ix->row_of_id, std::max(ix->row_of_id.size() + (size_t)(want - ix->n), 2 * ix->row_of_id.capacity()));
     } catch (const std::bad_alloc&) {
         return fail(LBH_E_NOMEM, "out of host memory");
     }
@@ -867,6 +887,10 @@ int lbh_shutdown(lbh_ctx* c) {
     if (c->memo_table) (void)hipFree(c->memo_table);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (int b = 0; b < LBH_STAGE_NBUF; ++b) {
+        if (c->stage_buf[b]) (void)hipHostFree(c->stage_buf[b]);
+        if (c->stage_ev[b]) (void)hipEventDestroy(c->stage_ev[b]);
+    }
     for (auto& ev : c->copy_ev)
         if (ev) (void)hipEventDestroy(ev);
     delete c;
@@ -898,6 +922,7 @@ int lbh_set_option(lbh_ctx* c, const char* name, int64_t value) {
         }
         c->memo_log2 = lg;
     }
+    else if (!strcmp(name, "stage_helpers")) c->stage_helpers = (int)std::max<int64_t>(1, std::min<int64_t>(LBH_STAGE_HELPERS, value));
     else if (!strcmp(name, "add_cuts")) {
         const int a = (int)(value / 10000 % 100), b = (int)(value / 100 % 100), d = (int)(value % 100);
         if (value != 0 && !(0 < a && a < b && b < d && d < 16)) return fail(LBH_E_INVALID, "add_cuts: need 0 < a < b < c < 16 as a * 10000 + b * 100 + c");
@@ -1035,12 +1060,155 @@ int lbh_index_reserve(lbh_index* ix, int64_t capacity) {
     return index_reserve_locked(ix, capacity);
 }
 
+}  // extern "C"
+
+namespace {
+// Host -> device copies of one lbh_index_add call.  Pinned sources (lbh_host_alloc) go to the copy engine as they are.
+// PAGEABLE sources -- ordinary numpy arrays, std::vectors: what the drop-in Python API hands over -- would be staged by
+// the runtime through its own bounce buffers by ONE thread (~20 GB/s: 8.3 ms for the 168 MB of a 1 M-claim batch, where
+// the link needs 2.9); here two helper threads copy them piece by piece (8 MiB) into a ring of pinned buffers (45 GB/s
+// between them, tools/stage_rate.py) while the calling thread hands finished pieces to the copy engine in order, so the
+// K1 slices still start as soon as their text has crossed.  Use: plan() every copy of the call in order, start(), then
+// copy() them in the same order; the destructor stops the helpers (also on an error return half-way).
+class StagedCopier {
+  public:
+    explicit StagedCopier(lbh_ctx* c) : c_(c) {}
+    StagedCopier(const StagedCopier&) = delete;
+    StagedCopier& operator=(const StagedCopier&) = delete;
+    ~StagedCopier() { stop(); }
+
+    void plan(const void* src, size_t bytes) {
+        Op op{src, bytes, pieces_.size(), 0};
+        if (bytes >= 65536 && pageable(src)) {
+            for (size_t off = 0; off < bytes; off += LBH_STAGE_PIECE) {
+                pieces_.push_back({static_cast<const uint8_t*>(src) + off, std::min(LBH_STAGE_PIECE, bytes - off)});
+                staged_bytes_ += pieces_.back().bytes;
+            }
+            op.n_pieces = pieces_.size() - op.first;
+        }
+        ops_.push_back(op);
+    }
+
+    int start() {
+        if (staged_bytes_ < ((size_t)4 << 20)) {  // small calls: the runtime's own staging is fine
+            for (auto& o : ops_) o.n_pieces = 0;
+            pieces_.clear();
+            return LBH_OK;
+        }
+        lk_ = std::unique_lock<std::mutex>(c_->stage_mu);
+        for (int b = 0; b < LBH_STAGE_NBUF; ++b) {
+            if (!c_->stage_buf[b]) HIP_TRY(hipHostMalloc(&c_->stage_buf[b], LBH_STAGE_PIECE, hipHostMallocDefault));
+            if (!c_->stage_ev[b]) HIP_TRY(hipEventCreateWithFlags(&c_->stage_ev[b], hipEventDisableTiming));
+        }
+        ready_.reset(new std::atomic<int>[pieces_.size()]);
+        issued_.reset(new std::atomic<int>[pieces_.size()]);
+        for (size_t i = 0; i < pieces_.size(); ++i) { ready_[i].store(0); issued_[i].store(0); }
+        nh_ = std::max(1, std::min(LBH_STAGE_HELPERS, c_->stage_helpers));
+        for (int h = 0; h < nh_; ++h) helpers_[h] = std::thread([this, h] { run_helper(h); });
+        started_ = true;
+        return LBH_OK;
+    }
+
+    int copy(void* dst, const void* src, size_t bytes, hipStream_t cs) {
+        if (next_op_ >= ops_.size() || ops_[next_op_].src != src || ops_[next_op_].bytes != bytes)
+            return fail(LBH_E_INTERNAL, "StagedCopier: copy %zu does not match the plan", next_op_);
+        const Op& op = ops_[next_op_++];
+        if (bytes == 0) return LBH_OK;
+        if (op.n_pieces == 0) {
+            HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs));
+            return LBH_OK;
+        }
+        size_t off = 0;
+        for (size_t i = op.first; i < op.first + op.n_pieces; ++i) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (!ready_[i].load(std::memory_order_acquire)) {
+                if (failed_.load()) return fail(LBH_E_DEVICE, "StagedCopier: a staging thread failed");
+                std::this_thread::yield();
+            }
+            const auto t1 = std::chrono::steady_clock::now();
+            const int b = (int)(i % LBH_STAGE_NBUF);
+            HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(dst) + off, c_->stage_buf[b], pieces_[i].bytes, hipMemcpyHostToDevice, cs));
+            HIP_TRY(hipEventRecord(c_->stage_ev[b], cs));
+            issued_[i].store(1, std::memory_order_release);
+            off += pieces_[i].bytes;
+            wait_us += std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
+            issue_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t1).count();
+        }
+        return LBH_OK;
+    }
+
+    // after the call's final synchronisation (or on the way out of a failed call, after the streams were drained by the
+    // caller's guard -- which is declared BEFORE this object, so it runs after this destructor: the helpers are stopped
+    // first, then the streams drain, then the ring is free for the next call)
+    void stop() {
+        abort_.store(true);
+        if (started_) {
+            for (auto& t : helpers_)
+                if (t.joinable()) t.join();
+            started_ = false;
+        }
+    }
+    // the ring must not be handed to the next call before this call's copies out of it have completed
+    void release_after_sync() {
+        stop();
+        if (lk_.owns_lock()) lk_.unlock();
+    }
+
+    long long wait_us = 0, issue_us = 0;  // (LBH_ADD_TRACE) time the calling thread spent waiting for staged pieces / inside the HIP calls
+
+  private:
+    struct Piece { const uint8_t* src; size_t bytes; };
+    struct Op { const void* src; size_t bytes; size_t first, n_pieces; };
+
+    static bool pageable(const void* p) {
+        hipPointerAttribute_t a;
+        const hipError_t e = hipPointerGetAttributes(&a, p);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();  // an unregistered pointer is reported as an error by older runtimes
+            return true;
+        }
+        return a.type == hipMemoryTypeUnregistered;
+    }
+
+    void run_helper(int h) {
+        (void)hipSetDevice(c_->device);
+        for (size_t i = (size_t)h; i < pieces_.size(); i += (size_t)nh_) {
+            const int b = (int)(i % LBH_STAGE_NBUF);
+            if (i >= LBH_STAGE_NBUF) {  // the piece that used this buffer last must have left it
+                while (!issued_[i - LBH_STAGE_NBUF].load(std::memory_order_acquire)) {
+                    if (abort_.load()) return;
+                    std::this_thread::yield();
+                }
+                if (hipEventSynchronize(c_->stage_ev[b]) != hipSuccess) { failed_.store(true); return; }
+            }
+            if (abort_.load()) return;
+            memcpy(c_->stage_buf[b], pieces_[i].src, pieces_[i].bytes);
+            ready_[i].store(1, std::memory_order_release);
+        }
+    }
+
+    lbh_ctx* c_;
+    std::vector<Piece> pieces_;
+    std::vector<Op> ops_;
+    size_t staged_bytes_ = 0, next_op_ = 0;
+    std::unique_ptr<std::atomic<int>[]> ready_, issued_;
+    std::atomic<bool> abort_{false}, failed_{false};
+    std::thread helpers_[LBH_STAGE_HELPERS];
+    std::unique_lock<std::mutex> lk_;
+    bool started_ = false;
+    int nh_ = 1;
+};
+}  // namespace
+
+extern "C" {
+
 int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t* utf8, const int64_t* offsets,
                   const int64_t* created_ms, const uint64_t* tagmask, const uint8_t* hashkey, uint64_t* out_ids) try {
     if (!ix || n < 0) return fail(LBH_E_INVALID, "bad argument");
     if (n == 0) return LBH_OK;
     if ((emb_f64 != nullptr) == (offsets != nullptr)) return fail(LBH_E_INVALID, "pass either emb_f64 or (utf8, offsets)");
     if (!created_ms || !hashkey) return fail(LBH_E_INVALID, "created_ms and hashkey are required");
+    const auto t_enter = std::chrono::steady_clock::now();
     Exclusive lk(ix);
     lbh_ctx* c = ix->ctx;
     HIP_TRY(hipSetDevice(c->device));
@@ -1060,17 +1228,30 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
     // Per-claim metadata goes straight from the caller's arrays to their device columns (asynchronous DMA when the
     // arrays are pinned -- lbh_host_alloc -- else the runtime stages them); the 32 key bytes are decoded into their four
     // big-endian words by a kernel, not by a host loop.
-    auto copy_metadata = [&](hipStream_t cs) -> int {
-        HIP_TRY(hipMemcpyAsync(ix->created + r0, created_ms, (size_t)n * 8, hipMemcpyHostToDevice, cs));
-        if (tagmask) HIP_TRY(hipMemcpyAsync(ix->tags + r0, tagmask, (size_t)n * 8, hipMemcpyHostToDevice, cs));
-        else HIP_TRY(hipMemsetAsync(ix->tags + r0, 0, (size_t)n * 8, cs));
-        HIP_TRY(hipMemcpyAsync(ix->keys + r0 * 4, hashkey, (size_t)n * 32, hipMemcpyHostToDevice, cs));
-        return LBH_OK;
+    // Every host -> device copy of the call goes through h2d(): the call's body runs twice, first to PLAN the copies
+    // (so that the staging threads of StagedCopier can run ahead through pageable buffers), then for real.
+    bool planning = true;
+    StagedCopier* scp = nullptr;
+    auto h2d = [&](void* dst, const void* src, size_t bytes, hipStream_t cs) -> int {
+        if (planning) {
+            scp->plan(src, bytes);
+            return LBH_OK;
+        }
+        return scp->copy(dst, src, bytes, cs);
     };
+    auto copy_metadata = [&](hipStream_t cs) -> int {
+        int rc = h2d(ix->created + r0, created_ms, (size_t)n * 8, cs);
+        if (rc) return rc;
+        if (tagmask) rc = h2d(ix->tags + r0, tagmask, (size_t)n * 8, cs);
+        else if (!planning) HIP_TRY(hipMemsetAsync(ix->tags + r0, 0, (size_t)n * 8, cs));
+        if (rc) return rc;
+        return h2d(ix->keys + r0 * 4, hashkey, (size_t)n * 32, cs);
+    };
+    const uint64_t id0 = (uint64_t)ix->row_of_id.size();  // first claim id of the batch
     auto finish_metadata = [&]() -> int {
         HIP_TRY(lbh_launch_bswap_u64(ix->keys + r0 * 4, n * 4, s));
-        HIP_TRY(lbh_launch_iota_u64(ix->order + r0, (uint64_t)ix->row_of_id.size(), n, s));
-        HIP_TRY(lbh_launch_iota_u64(ix->ids + r0, (uint64_t)ix->row_of_id.size(), n, s));
+        HIP_TRY(lbh_launch_iota_u64(ix->order + r0, id0, n, s));
+        HIP_TRY(lbh_launch_iota_u64(ix->ids + r0, id0, n, s));
         return LBH_OK;
     };
     double batch_norm = 1.0;  // K1 writes unit vectors (or zero)
@@ -1088,15 +1269,78 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
             (void)hipStreamSynchronize(c->stream);
         }
     } drain{c};
+    StagedCopier sc(c);  // (after `drain`: its helpers stop before the streams are drained on an error return)
+    scp = &sc;
+    // The host-side id maps (a million entries per large batch: 1-2 ms) are brought up to date by a thread of their own
+    // while this one feeds the copy engine -- with pageable buffers it is busy handing over staged pieces until the last
+    // byte has left, and the maps used to wait for that.  The vectors were reserved above (no re-allocation here); every
+    // return before the call is committed shrinks them again.
+    struct IdMapJob {
+        lbh_index* ix;
+        int64_t n, r0;
+        uint64_t id0;
+        uint64_t* out_ids;
+        std::thread th;
+        bool started = false, committed = false;
+        void start() {
+            started = true;
+            auto fill = [this] {
+                ix->row_of_id.resize((size_t)id0 + (size_t)n);  // (capacity reserved by the caller: no allocation, no exception)
+                ix->id_of_row.resize((size_t)(r0 + n));
+                for (int64_t i = 0; i < n; ++i) {
+                    ix->row_of_id[(size_t)(id0 + i)] = r0 + i;
+                    ix->id_of_row[(size_t)(r0 + i)] = id0 + (uint64_t)i;
+                    if (out_ids) out_ids[i] = id0 + (uint64_t)i;
+                }
+            };
+            if (n >= 65536) th = std::thread(fill);
+            else fill();
+        }
+        void join() { if (th.joinable()) th.join(); }
+        ~IdMapJob() {
+            join();
+            if (started && !committed) {
+                ix->row_of_id.resize((size_t)id0);
+                ix->id_of_row.resize((size_t)r0);
+            }
+        }
+    } idmap{ix, n, r0, id0, out_ids, {}};
     if (emb_f64) {
         batch_norm = 0.0;
-        for (int64_t i = 0; i < n; ++i) batch_norm = std::max(batch_norm, vec_norm(emb_f64 + i * 64));
+        {   // largest norm of the batch (non-finite values make it NaN or inf): a million rows take 30 ms on one thread
+            const int nt = n >= 65536 ? 4 : 1;
+            double part[4] = {0.0, 0.0, 0.0, 0.0};
+            auto work = [&](int t) {
+                double m = 0.0;
+                bool bad = false;
+                for (int64_t i = n * t / nt; i < n * (t + 1) / nt; ++i) {
+                    const double v = vec_norm(emb_f64 + i * 64);
+                    if (!(v <= 1e15)) bad = true;
+                    m = std::max(m, v);
+                }
+                part[t] = bad ? std::numeric_limits<double>::infinity() : m;
+            };
+            std::thread th[3];
+            for (int t = 1; t < nt; ++t) th[t - 1] = std::thread(work, t);
+            work(0);
+            for (int t = 1; t < nt; ++t) th[t - 1].join();
+            for (int t = 0; t < nt; ++t) batch_norm = std::max(batch_norm, part[t]);
+        }
         if (!(batch_norm <= 1e15)) return fail(LBH_E_INVALID, "a vector is not finite (or its norm exceeds 1e15)");
-        int rc = copy_metadata(s);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(ix->emb64 + r0 * 64, emb_f64, (size_t)n * 512, hipMemcpyHostToDevice, s));
+        for (int pass = 0; pass < 2; ++pass) {
+            planning = pass == 0;
+            int rc = copy_metadata(s);
+            if (rc) return rc;
+            rc = h2d(ix->emb64 + r0 * 64, emb_f64, (size_t)n * 512, s);
+            if (rc) return rc;
+            if (planning) {
+                rc = sc.start();
+                if (rc) return rc;
+                idmap.start();
+            }
+        }
         HIP_TRY(lbh_launch_f64_to_f32(ix->emb64 + r0 * 64, ix->emb32 + r0 * 64, n * 64, s));
-        rc = finish_metadata();
+        int rc = finish_metadata();
         if (rc) return rc;
     } else {
         const int64_t base = offsets[0], bytes = offsets[n] - base;
@@ -1132,45 +1376,65 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
             cut16[3][3] = c->add_cuts % 100;
         }
         const int n_sl = (int)std::max<int64_t>(1, std::min<int64_t>(LBH_ADD_SLICES, n / 65536));
-        for (int sl = 0; sl < n_sl; ++sl) {
-            const int64_t a = n * cut16[n_sl - 1][sl] / 16, b2 = n * cut16[n_sl - 1][sl + 1] / 16;
-            const int64_t t0 = offp[a], t1 = offp[b2];
-            if (t1 > t0) HIP_TRY(hipMemcpyAsync(c->d_text + t0, utf8 + base + t0, (size_t)(t1 - t0), hipMemcpyHostToDevice, c->copy_stream));
-            HIP_TRY(hipMemcpyAsync(c->d_off + a, offp + a, (size_t)(b2 - a + 1) * 8, hipMemcpyHostToDevice, c->copy_stream));
-            HIP_TRY(hipEventRecord(c->copy_ev[sl], c->copy_stream));
-            HIP_TRY(hipStreamWaitEvent(s, c->copy_ev[sl], 0));
-            const lbh_memo memo = next_memo(c, b2 - a);  // (text_lk holds c->mu)
-            HIP_TRY(lbh_launch_embed(c->d_text, c->d_off + a, b2 - a, ix->emb64 + (r0 + a) * 64, ix->emb32 + (r0 + a) * 64, s, LBH_DIM, &memo));
-            if (sl == n_sl - 1) {
-                rc = copy_metadata(c->copy_stream);
+        for (int pass = 0; pass < 2; ++pass) {
+            planning = pass == 0;
+            for (int sl = 0; sl < n_sl; ++sl) {
+                const int64_t a = n * cut16[n_sl - 1][sl] / 16, b2 = n * cut16[n_sl - 1][sl + 1] / 16;
+                const int64_t t0 = offp[a], t1 = offp[b2];
+                if (t1 > t0) {
+                    rc = h2d(c->d_text + t0, utf8 + base + t0, (size_t)(t1 - t0), c->copy_stream);
+                    if (rc) return rc;
+                }
+                rc = h2d(c->d_off + a, offp + a, (size_t)(b2 - a + 1) * 8, c->copy_stream);
                 if (rc) return rc;
-                HIP_TRY(hipEventRecord(c->copy_ev[LBH_ADD_SLICES], c->copy_stream));
-                HIP_TRY(hipStreamWaitEvent(s, c->copy_ev[LBH_ADD_SLICES], 0));
+                if (!planning) {
+                    HIP_TRY(hipEventRecord(c->copy_ev[sl], c->copy_stream));
+                    HIP_TRY(hipStreamWaitEvent(s, c->copy_ev[sl], 0));
+                    const lbh_memo memo = next_memo(c, b2 - a);  // (text_lk holds c->mu)
+                    HIP_TRY(lbh_launch_embed(c->d_text, c->d_off + a, b2 - a, ix->emb64 + (r0 + a) * 64, ix->emb32 + (r0 + a) * 64, s, LBH_DIM, &memo));
+                }
+                if (sl == n_sl - 1) {
+                    rc = copy_metadata(c->copy_stream);
+                    if (rc) return rc;
+                    if (!planning) {
+                        HIP_TRY(hipEventRecord(c->copy_ev[LBH_ADD_SLICES], c->copy_stream));
+                        HIP_TRY(hipStreamWaitEvent(s, c->copy_ev[LBH_ADD_SLICES], 0));
+                    }
+                }
+            }
+            if (planning) {
+                rc = sc.start();
+                if (rc) return rc;
+                idmap.start();
             }
         }
         rc = finish_metadata();
         if (rc) return rc;
     }
-    const uint64_t id0 = (uint64_t)ix->row_of_id.size();
-    ix->row_of_id.resize(ix->row_of_id.size() + (size_t)n);
-    ix->id_of_row.resize((size_t)(r0 + n));
-    for (int64_t i = 0; i < n; ++i) {
-        ix->row_of_id[(size_t)(id0 + i)] = r0 + i;
-        ix->id_of_row[(size_t)(r0 + i)] = id0 + (uint64_t)i;
-        if (out_ids) out_ids[i] = id0 + (uint64_t)i;
-    }
+    static const bool add_trace = getenv("LBH_ADD_TRACE") != nullptr;  // debugging aid: where a call's time goes
+    const auto t_issued = std::chrono::steady_clock::now();
+    idmap.join();
+    const auto t_joined = std::chrono::steady_clock::now();
     ix->n += n;
     ix->max_norm = std::max(ix->max_norm, batch_norm);
     // ONE synchronisation per call, after the host-side id maps were brought up to date under the GPU's work: the
     // caller's buffers (and `rel`) are free again when this returns
     const hipError_t e_sync = hipStreamSynchronize(s);
+    if (add_trace) {
+        const auto t_synced = std::chrono::steady_clock::now();
+        auto us = [&](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return (long long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count();
+        };
+        fprintf(stderr, "lbh_index_add n=%lld: copies issued +%lld us (waiting for staged pieces %lld, in HIP calls %lld), id maps joined +%lld us, streams idle +%lld us\n",
+                (long long)n, us(t_enter, t_issued), sc.wait_us, sc.issue_us, us(t_issued, t_joined), us(t_joined, t_synced));
+    }
     drain.armed = false;  // `s` waited on every copy-stream event: both streams are idle
-    if (e_sync != hipSuccess) {  // the rows are not usable: take them back
+    sc.release_after_sync();  // ... and so is the staging ring
+    if (e_sync != hipSuccess) {  // the rows are not usable: take them back (idmap's destructor shrinks the maps again)
         ix->n -= n;
-        ix->row_of_id.resize((size_t)id0);
-        ix->id_of_row.resize((size_t)r0);
         return fail(LBH_E_DEVICE, "lbh_index_add: %s", hipGetErrorString(e_sync));
     }
+    idmap.committed = true;
     return LBH_OK;
 } LBH_CATCH_ALLOC
 
