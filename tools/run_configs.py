@@ -66,7 +66,7 @@ def ingest_prepacked(n_chunks=4, chunk=1_000_000):
             "pinned_call_ms": [round(1e3 * t, 3) for t in pin_calls], "pageable_call_ms": [round(1e3 * t, 3) for t in page_calls],
             "pinned_buffers_claims_per_s_median_call": chunk / float(np.median(pin_calls)),
             "pageable_buffers_claims_per_s_median_call": chunk / float(np.median(page_calls)),
-            "note": "1 M-claim calls, ~112 B of text + 56 B of metadata per claim; K1 alone runs at ~243 M claims/s; every chunk is added, retracted whole and added again, so the id map doubles now and then (the slow call)"}
+            "note": "1 M-claim calls, ~112 B of text + 56 B of metadata per claim; K1 alone runs at ~430 M claims/s (token memo warm); every chunk is added, retracted whole and added again, so the id map doubles now and then (the slow call)"}
 
 
 def time_single(ix, qv, k, since, tmask, reps=60):
