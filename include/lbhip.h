@@ -86,7 +86,8 @@ int lbh_device_name(lbh_ctx* ctx, char* buf, int buflen);
  * for grids of one block per CU on indexes up to 4 M claims, the default / always), "scan_xb_k" (smallest top_k for
  * which the scan's waves share a cross-block threshold at their compactions, default 24, 0 = never), "k1_memo_log2"
  * (log2 of the entries of the vectoriser's token -> digest table, default 20 = 128 MiB of HBM, 0 = off),
- * "spin_us" (completion-ticket polling budget), "coll_timeout_ms" (longest wait for a
+ * "stage_helpers" (1..8, default 2: threads that copy PAGEABLE caller buffers of lbh_index_add into its pinned staging
+ * ring; pinned buffers -- lbh_host_alloc -- need none), "spin_us" (completion-ticket polling budget), "coll_timeout_ms" (longest wait for a
  * claim-sharded search's all-gather; also LBH_COLL_TIMEOUT_MS), "force_exact" (0/1, diagnostic: single-query searches rank with the exact fp64 scan only -- the
  * path that otherwise serves mass ties and result pages beyond the first), "inject_fault" (test hook, one-shot: 1 = the next
  * sharded search's local part fails on this rank, 2 = its stream is held up past the timeout).  Also read from the
@@ -97,7 +98,8 @@ int lbh_set_option(lbh_ctx* ctx, const char* name, int64_t value);
 
 /* Pinned (page-locked) host memory for the arrays handed to lbh_index_add / lbh_embed_batch (no reference counterpart:
  * an ingest-rate helper).  From pinned buffers the text, offsets, timestamps, tag masks and keys cross PCIe by
- * asynchronous DMA that overlaps the vectorising kernel; ordinary (pageable) buffers work everywhere, only slower. */
+ * asynchronous DMA that overlaps the vectorising kernel; ordinary (pageable) buffers work everywhere -- lbh_index_add
+ * stages them itself through a ring of pinned pieces filled by helper threads (4.1 against 3.4 ms per million claims). */
 int lbh_host_alloc(lbh_ctx* ctx, int64_t bytes, void** out_ptr);
 int lbh_host_free(lbh_ctx* ctx, void* ptr);
 
