@@ -538,6 +538,22 @@ __global__ void bswap_u64_kernel(uint64_t* p, int64_t n) {
         p[i] = __builtin_bswap64(p[i]);
 }
 
+// Metadata of a SMALL batch (lbh_index_add, n <= 256 = one block) straight from device-mapped host memory: timestamps, tag masks, the
+// 32 key bytes as four big-endian words, order stamps and claim ids of rows r0 .. r0 + n - 1 -- one launch where the
+// bulk path makes three copies and three kernels.
+__global__ void small_meta_kernel(const int64_t* __restrict__ created_src, const uint64_t* __restrict__ tags_src,
+                                  const uint64_t* __restrict__ keys_src, int64_t* created, uint64_t* tags, uint64_t* keys,
+                                  uint64_t* order, uint64_t* ids, int64_t r0, uint64_t id0, int n) {
+    const int t = threadIdx.x;
+    for (int i = t; i < n * 4; i += blockDim.x) keys[r0 * 4 + i] = __builtin_bswap64(keys_src[i]);
+    if (t < n) {
+        created[r0 + t] = created_src[t];
+        tags[r0 + t] = tags_src ? tags_src[t] : 0ull;
+        order[r0 + t] = id0 + (uint64_t)t;
+        ids[r0 + t] = id0 + (uint64_t)t;
+    }
+}
+
 // dst[rows[i]] = vals[i]  (rows are distinct: one claim id maps to one row)
 __global__ void scatter_u64_kernel(uint64_t* dst, const int64_t* __restrict__ rows, const uint64_t* __restrict__ vals, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -579,6 +595,13 @@ hipError_t lbh_launch_move_rows(float* emb32, double* emb64, uint16_t* emb16, in
                                 uint64_t* order, uint64_t* ids, const int64_t* pairs_dev, int64_t n_pairs, hipStream_t s) {
     if (n_pairs <= 0) return hipSuccess;
     move_rows_kernel<<<dim3((unsigned)((n_pairs + 3) / 4)), 256, 0, s>>>(emb32, emb64, emb16, emb8, created, tags, keys, order, ids, pairs_dev, n_pairs);
+    return hipGetLastError();
+}
+
+hipError_t lbh_launch_small_meta(const int64_t* created_src, const uint64_t* tags_src, const uint64_t* keys_src, int64_t* created,
+                                 uint64_t* tags, uint64_t* keys, uint64_t* order, uint64_t* ids, int64_t r0, uint64_t id0, int n,
+                                 hipStream_t s) {
+    small_meta_kernel<<<1, 256, 0, s>>>(created_src, tags_src, keys_src, created, tags, keys, order, ids, r0, id0, n);
     return hipGetLastError();
 }
 

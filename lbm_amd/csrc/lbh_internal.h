@@ -201,6 +201,9 @@ hipError_t lbh_launch_move_row(float* emb32, double* emb64, uint16_t* emb16, int
                                uint64_t* order, uint64_t* ids, int64_t dst, int64_t src, hipStream_t s);
 hipError_t lbh_launch_move_rows(float* emb32, double* emb64, uint16_t* emb16, int8_t* emb8, int64_t* created, uint64_t* tags, uint64_t* keys,
                                 uint64_t* order, uint64_t* ids, const int64_t* pairs_dev, int64_t n_pairs, hipStream_t s);
+hipError_t lbh_launch_small_meta(const int64_t* created_src, const uint64_t* tags_src, const uint64_t* keys_src, int64_t* created,
+                                 uint64_t* tags, uint64_t* keys, uint64_t* order, uint64_t* ids, int64_t r0, uint64_t id0, int n,
+                                 hipStream_t s);
 // int8 copy: largest |element| of rows [row0, row1) as float bits, raised into *out_bits_dev by atomicMax; then the conversion
 hipError_t lbh_launch_absmax_f64(const double* emb64_dev, int64_t row0, int64_t row1, uint32_t* out_bits_dev, hipStream_t s);
 hipError_t lbh_launch_f64_to_i8_tiled(const double* emb64_dev, int8_t* emb8_dev, int64_t row0, int64_t row1, double inv_scale, hipStream_t s);
