@@ -308,3 +308,44 @@ def test_select_flavours_agree_two_kernels_fused_and_fused_on_a_large_grid(hip):
         hip.set_option("scan_blocks_per_cu", 0)
         hip.set_option("force_exact", 0)
         ix.close()
+
+
+def test_small_and_bulk_ingest_paths_give_the_same_index(hip):
+    """lbh_index_add takes batches of up to 256 claims / 40 KB of text through one device-mapped block and two launches,
+    anything larger through the sliced bulk path (pageable buffers: the staging ring).  Either way the rows must carry the
+    oracle's embedding bits, their timestamps, tag masks, keys and ids -- checked at the sizes where the path switches,
+    with empty texts, no tag masks, and a small batch whose text alone is too long for the block."""
+    from lbm_amd import synth
+    rng = np.random.default_rng(3)
+    ch = synth.make_chunk(0, 3000, seed=5, real_sha_keys=False)
+    ix = hip.Index()
+    all_ids, all_texts, all_created, all_tags, all_keys = [], [], [], [], []
+    pos = 0
+    for m in (1, 63, 64, 65, 255, 256, 257, 2, 300, 1):
+        texts = [ch.text(pos + i) if (pos + i) % 17 else "" for i in range(m)]
+        if m == 2:
+            texts[1] = " ".join("w%05d" % int(x) for x in rng.integers(0, 90000, size=7000))  # ~49 KB: too long for the block
+        blob = np.frombuffer("".join(texts).encode() + b"\x00", dtype=np.uint8).copy()
+        offs = np.zeros(m + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([len(t.encode()) for t in texts])
+        created = ch.created_ms[pos:pos + m].copy()
+        tags = None if m in (64, 257) else ch.tagmask[pos:pos + m].copy()
+        keys = ch.keys[pos:pos + m].copy()
+        ids = ix.add_texts(blob, offs, created, tags, keys)
+        assert ids.tolist() == list(range(len(all_texts), len(all_texts) + m))
+        all_ids += ids.tolist(); all_texts += texts; all_created += created.tolist()
+        all_tags += (np.zeros(m, np.uint64) if tags is None else tags).tolist(); all_keys.append(keys)
+        pos += m
+    n = len(all_texts)
+    want = orc.embed_batch(all_texts)
+    got = ix.get_embeddings(np.array(all_ids, dtype=np.uint64))
+    assert got.tobytes() == want.tobytes()
+    keys = np.concatenate(all_keys)
+    hexes = [bytes(r).hex() for r in keys]
+    created, tagm = np.array(all_created, dtype=np.int64), np.array(all_tags, dtype=np.uint64)
+    for q, k, since, tm in ((all_texts[5], 20, None, 0), (all_texts[400], 64, int(np.median(created)), 0), (all_texts[1100], 9, None, 0b1110)):
+        qv = orc.embed_array(q)
+        oi, osc = orc.compile_arrays(want, created, np.zeros(n, np.uint8), hexes, qv, k, since, tagm, tm)
+        gi, gs, gk = ix.search_shard(qv, k, hip.SINCE_NONE if since is None else since, tm)
+        assert gi.tolist() == oi.tolist() and gs.tobytes() == osc.tobytes() and gk.tobytes() == keys[oi].tobytes()
+    ix.close()
