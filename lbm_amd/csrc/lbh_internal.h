@@ -19,6 +19,7 @@
 #define LBH_BQ_QT_STRIDE 32                     // ints between two queries' list counters (one cache line each)
 #define LBH_BQ_KMAX 16                          // largest top_k the batched path serves
 #define LBH_MAX_BLOCKS 2048                     // max scan grid (lists in the workspace)
+#define LBH_BBEST_SLOTS 1024                    // blocks whose best score the two-kernel scan leaves for the select kernel's cut (bmax[0 .. ) as 64-bit words)
 #define LBH_XB_SLOTS 512                        // blocks that publish their best score for the cross-block bound (K2, large k)
 
 // fp32 scan vs reference fp64 score: rigorous bound on |s32 - s64| is < 4e-6 for unit 64-vectors

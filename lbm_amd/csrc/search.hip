@@ -652,6 +652,8 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
             }
             my_ns = ns;
             if (total >= k) publish_cut(own);
+            if (!fuse && bcnt && lane == 0 && (int)blockIdx.x < LBH_BBEST_SLOTS)  // the block's best score, for the select kernel's cut
+                reinterpret_cast<unsigned long long*>(bcnt)[blockIdx.x] = ((unsigned long long)(uint32_t)seq << 32) | (uint32_t)(mbuf[0] >> 32);
             K2_STAMP(5);
         }
     } else {
@@ -692,6 +694,8 @@ __global__ __launch_bounds__(LBH_SCAN_THREADS) void scan_f32_kernel(lbh_dev_inde
         }
         my_ns = ns;
         if (wave == 0 && total >= k) publish_cut(own_cut);
+        if (!fuse && bcnt && threadIdx.x == 0 && (int)blockIdx.x < LBH_BBEST_SLOTS)
+            reinterpret_cast<unsigned long long*>(bcnt)[blockIdx.x] = ((unsigned long long)(uint32_t)seq << 32) | (uint32_t)(mbuf[0] >> 32);
     }
     }
     if (!fuse) return;
@@ -1286,12 +1290,13 @@ __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index 
                                                                    lbh_qarg qa, int k,
                                                                    const uint64_t* __restrict__ cand,
                                                                    int32_t* __restrict__ flags,
-                                                                   lbh_result* __restrict__ res, int seq, float margin, lbh_xchg xc) {
+                                                                   lbh_result* __restrict__ res, int seq, float margin, lbh_xchg xc,
+                                                                   const unsigned long long* __restrict__ bbest, int n_blocks) {
     __shared__ double qs[64];
     const int tid = threadIdx.x;
     K4_STAMP(0);
     const int overflowed = flags[0];
-    const int E = flags[1];
+    int E = flags[1];
     if (tid < 64) qs[tid] = qptr ? qptr[tid] : qa.q[tid];
     __syncthreads();
     K4_STAMP(1);  // counters read
@@ -1303,7 +1308,48 @@ __global__ __launch_bounds__(SEL_THREADS) void select_fast_kernel(lbh_dev_index 
     if (overflowed) {
         if (tid == 0) { res->count = 0; res->overflow = 1; res->candidates = 0; }
     } else {
-        select_fast_body(ix, qs, k, cand, E, res, margin, xc);
+        // A sharper cut before anything is sorted or selected (round 3): every scan block left its BEST score (launch-tagged,
+        // bbest[block]); the k-th largest of those belongs to k different rows, so the corpus's k-th best is at least that,
+        // a bound only a few ranks below it -- where the blocks' own cuts let 1 500-2 000 entries into the flat list, ~10
+        // pass this one, and those go to the short-list select (one wave, no sort) instead of the radix select.
+        __shared__ uint32_t bm[LBH_BBEST_SLOTS];
+        __shared__ uint64_t pre_stage[2048];
+        __shared__ uint32_t sh_pre;
+        __shared__ int sh_pn;
+        const uint64_t* list = cand;
+        if (bbest && E > 512 && n_blocks >= k) {  // (a list that short is ranked whole faster than the bound is found)
+            const int GB = n_blocks < LBH_BBEST_SLOTS ? n_blocks : LBH_BBEST_SLOTS;
+            for (int b = tid; b < LBH_BBEST_SLOTS; b += SEL_THREADS) {
+                const unsigned long long w = b < GB ? bbest[b] : 0ull;
+                bm[b] = (uint32_t)(w >> 32) == (uint32_t)seq ? (uint32_t)w : 0u;
+            }
+            if (tid == 0) { sh_pre = 0; sh_pn = 0; }
+            __syncthreads();
+            if (tid < 64) {
+                uint32_t v[LBH_BBEST_SLOTS / 64];
+#pragma unroll
+                for (int i = 0; i < LBH_BBEST_SLOTS / 64; ++i) v[i] = bm[i * 64 + tid];
+                const uint32_t kth = wave_kth_bound<LBH_BBEST_SLOTS / 64, 12>(v, k);
+                if (tid == 0 && kth) sh_pre = lbh_ord32(lbh_unord32(kth) - margin);
+            }
+            __syncthreads();
+            const uint32_t precut = sh_pre;
+            if (precut) {
+                for (int e = tid; e < E; e += SEL_THREADS) {
+                    const uint64_t v = cand[e];
+                    if ((uint32_t)(v >> 32) >= precut) {
+                        const int pos = atomicAdd(&sh_pn, 1);
+                        if (pos < 2048) pre_stage[pos] = v;
+                    }
+                }
+                __syncthreads();
+                if (sh_pn <= 2048) {  // (else: mass near-ties -- the full list goes through the usual path)
+                    list = pre_stage;
+                    E = sh_pn;
+                }
+            }
+        }
+        select_fast_body(ix, qs, k, list, E, res, margin, xc);
     }
     K4_STAMP(6);  // result rows written
     publish_result(res, seq);
@@ -2935,7 +2981,8 @@ hipError_t lbh_launch_search_fast(const lbh_dev_index& ix, const uint16_t* emb16
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (fuse) return hipSuccess;  // the scan's last block publishes the result
-    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, qptr, qa, k, ws.cand, ws.flags, ws.result_dev, seq, margin, xcv);
+    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, qptr, qa, k, ws.cand, ws.flags, ws.result_dev, seq, margin, xcv,
+                                                 reinterpret_cast<const unsigned long long*>(ws.bmax), grid);
     return hipGetLastError();
 }
 
@@ -3046,7 +3093,7 @@ hipError_t lbh_launch_search_noalloc(void* scratch_ptr, const lbh_dev_index& ix,
         else scan_f32_kernel<false, false, false, false, false><<<g, b, 0, s>>>(LBH_NA_ARGS);
     }
 #undef LBH_NA_ARGS
-    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, nullptr, qa, k, cand, flags, res, 1, margin, lbh_xchg{nullptr, 0, 0});
+    select_fast_kernel<<<1, SEL_THREADS, 0, s>>>(ix, nullptr, qa, k, cand, flags, res, 1, margin, lbh_xchg{nullptr, 0, 0}, nullptr, 0);
     // mass near-ties (res->overflow == 1): the exact fp64 path decides; both kernels return at once otherwise.  No host
     // round trip in between, so the whole sequence is stream-ordered.
     lbh_cursor cur;
