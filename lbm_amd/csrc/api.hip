@@ -16,6 +16,7 @@
 #include <shared_mutex>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <atomic>
 #include <memory>
@@ -1109,8 +1110,16 @@ class StagedCopier {
         issued_.reset(new std::atomic<int>[pieces_.size()]);
         for (size_t i = 0; i < pieces_.size(); ++i) { ready_[i].store(0); issued_[i].store(0); }
         nh_ = std::max(1, std::min(LBH_STAGE_HELPERS, c_->stage_helpers));
-        for (int h = 0; h < nh_; ++h) helpers_[h] = std::thread([this, h] { run_helper(h); });
         started_ = true;
+        try {
+            for (int h = 0; h < nh_; ++h) helpers_[h] = std::thread([this, h] { run_helper(h); });
+        } catch (const std::system_error&) {  // no thread to be had: stop the ones that started, let the runtime stage the copies
+            stop();
+            abort_.store(false);
+            for (auto& o : ops_) o.n_pieces = 0;
+            pieces_.clear();
+            lk_.unlock();
+        }
         return LBH_OK;
     }
 
@@ -1347,8 +1356,11 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
                     if (out_ids) out_ids[i] = id0 + (uint64_t)i;
                 }
             };
-            if (n >= 65536) th = std::thread(fill);
-            else fill();
+            bool own_thread = n >= 65536;
+            if (own_thread) {
+                try { th = std::thread(fill); } catch (const std::system_error&) { own_thread = false; }
+            }
+            if (!own_thread) fill();
         }
         void join() { if (th.joinable()) th.join(); }
         ~IdMapJob() {
@@ -1375,9 +1387,15 @@ int lbh_index_add(lbh_index* ix, int64_t n, const double* emb_f64, const uint8_t
                 part[t] = bad ? std::numeric_limits<double>::infinity() : m;
             };
             std::thread th[3];
-            for (int t = 1; t < nt; ++t) th[t - 1] = std::thread(work, t);
+            bool inl[3] = {false, false, false};
+            for (int t = 1; t < nt; ++t) {
+                try { th[t - 1] = std::thread(work, t); } catch (const std::system_error&) { inl[t - 1] = true; }
+            }
             work(0);
-            for (int t = 1; t < nt; ++t) th[t - 1].join();
+            for (int t = 1; t < nt; ++t) {
+                if (inl[t - 1]) work(t);
+                else th[t - 1].join();
+            }
             for (int t = 0; t < nt; ++t) batch_norm = std::max(batch_norm, part[t]);
         }
         if (!(batch_norm <= 1e15)) return fail(LBH_E_INVALID, "a vector is not finite (or its norm exceeds 1e15)");
