@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 ROUNDS = int(os.environ.get("LBM_FUZZ_ROUNDS", "12"))
 SEED0 = int(os.environ.get("LBM_FUZZ_SEED", "0"))  # campaigns beyond the default seeds
 SIZES = [1, 2, 63, 64, 65, 700, 5000, 40_000] + ([300_000] if os.environ.get("LBM_FUZZ_BIG") else [])
+SCAN_FUSE = os.environ.get("LBM_FUZZ_SCAN_FUSE")  # campaigns over one select flavour: 0 = two kernels, 2 = fused at every size
 
 
 def _corpus(rng, n, kind):
@@ -80,6 +81,8 @@ def test_search_paths_vs_oracle(seed):
     tmask = 0 if rng.random() < 0.6 else int(rng.integers(1, 256))
     want = [orc.compile_arrays(emb, created, retr, None, q[j], k, since, tagmask, tmask, packed_keys=packed) for j in range(nq)]
     st = hip.Stats()
+    if SCAN_FUSE is not None:
+        hip.set_option("scan_fuse", int(SCAN_FUSE))
     for smode in (0, 1):  # single-query path (fast scan over the fp32 matrix or the fp16 copy, exact fallback, paging)
         hip.set_option("scan_mode", smode)
         for j in range(nq):
