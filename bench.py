@@ -452,12 +452,22 @@ def main():
     if world == 1 and args.cc_steps > 0 and host_chunks:
         from lbm_amd.context_graph import format_context
 
+        # The claim store of this leg: the generated chunks as they are (a dict of 10 M Claim objects would not be the
+        # thing measured).  Buffer views, so that fetching a chosen claim costs what a dict lookup of a stored Claim
+        # would (indexing the numpy arrays per element and testing all 64 tag bits took longer than the formatting).
+        tag_names = ["t%02d" % b for b in range(64)]
+        views = [(memoryview(b), memoryview(o), memoryview(np.ascontiguousarray(k).reshape(-1)), memoryview(t))
+                 for b, o, k, t in host_chunks]
+
         def claim(cid):  # claim id = position in the generated corpus (ids are handed out in insertion order)
-            blob, off, keys, tagmask = host_chunks[cid // chunk]
+            blob, off, keys, tagmask = views[cid // chunk]
             j = cid % chunk
-            m = int(tagmask[j])
-            return (bytes(keys[j]).hex(), bytes(blob[off[j]: off[j + 1]]).decode("ascii"),
-                    ["t%02d" % b for b in range(64) if (m >> b) & 1])
+            m, tags = tagmask[j], []
+            while m:
+                low = m & -m
+                tags.append(tag_names[low.bit_length() - 1])
+                m ^= low
+            return keys[32 * j: 32 * j + 32].hex(), str(blob[off[j]: off[j + 1]], "ascii"), tags
 
         def compile_context(query):  # lb/node.py:718-734 -> lb/context_graph.py:104-133 on the HBM index
             ids, _, _ = ix.search_text(query, args.top_k, since, 0)  # embed(query) + scan + exact top-k: one call, one wait
